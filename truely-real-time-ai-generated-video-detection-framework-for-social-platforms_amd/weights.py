@@ -1,0 +1,298 @@
+"""Weight handling for the MI355X hot path.
+
+The reference builds its two models on every call
+(``MTCNN()`` / ``InceptionResnetV1(pretrained="vggface2").eval()``, server/model.py:18-19) from
+facenet-pytorch checkpoints.  Here the four ``state_dict``s (same key layout as
+facenet_pytorch==2.6.0) are packed ONCE into a flat "TRLW0001" blob:
+
+* conv / linear weights transposed OIHW -> [K][Cout] with ``k = (ky*KW + kx)*Cin + c`` (the
+  B operand of the NHWC implicit GEMM; ascending k is the accumulation order of the kernels),
+* R/O-Net dense weights re-ordered from torch's ``x.permute(0,3,2,1)`` (W,H,C) flatten order to
+  NHWC (H,W,C), so a dense layer is a "valid" KHxKW conv over the whole 3x3 map,
+* BatchNorm (eval, eps=1e-3) folded to per-channel (scale, shift) the way ATen's CPU kernel
+  does: ``alpha = weight * 1/sqrt(var+eps)``, ``beta = bias - mean*alpha`` in float32.
+
+There is no network and no checkpoint in the build container, so :func:`synthetic_state_dicts`
+produces seeded random weights of the right architecture; real checkpoints drop in through the
+same :func:`pack_state_dicts`.
+"""
+from __future__ import annotations
+
+import os
+import struct
+from typing import Dict, Mapping
+
+import numpy as np
+
+MAGIC = b"TRLW0001"
+_ENTRY = struct.Struct("<56sI4I4xQQ")  # name, ndim, dims[4], offset, nbytes  (96 bytes)
+BN_EPS = np.float32(1e-3)
+
+
+def _np(t) -> np.ndarray:
+    if isinstance(t, np.ndarray):
+        return t
+    if hasattr(t, "detach"):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def _conv_w(w) -> np.ndarray:
+    """OIHW -> [KH*KW*Cin, Cout]."""
+    w = _np(w).astype(np.float32)
+    co, ci, kh, kw = w.shape
+    return np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(kh * kw * ci, co))
+
+
+def _dense_w(w, c: int, h: int, wd: int) -> np.ndarray:
+    """Linear [out, (w*H+h)*C+c] -> [(h*W+w)*C+c, out]."""
+    w = _np(w).astype(np.float32)
+    out = w.shape[0]
+    w = w.reshape(out, wd, h, c).transpose(2, 1, 3, 0)  # h, w, c, out
+    return np.ascontiguousarray(w.reshape(h * wd * c, out))
+
+
+def _fold_bn(sd: Mapping, prefix: str):
+    g = _np(sd[prefix + ".weight"]).astype(np.float32)
+    b = _np(sd[prefix + ".bias"]).astype(np.float32)
+    m = _np(sd[prefix + ".running_mean"]).astype(np.float32)
+    v = _np(sd[prefix + ".running_var"]).astype(np.float32)
+    invstd = (np.float32(1.0) / np.sqrt(v + BN_EPS)).astype(np.float32)
+    alpha = (g * invstd).astype(np.float32)
+    beta = (b - m * alpha).astype(np.float32)
+    return alpha, beta
+
+
+# ---- architecture tables -------------------------------------------------------------------
+
+def facenet_basic_convs():
+    """Names of every BasicConv2d (conv+bn+relu) in InceptionResnetV1, torch module paths."""
+    names = ["conv2d_1a", "conv2d_2a", "conv2d_2b", "conv2d_3b", "conv2d_4a", "conv2d_4b"]
+    for i in range(5):
+        p = f"repeat_1.{i}"
+        names += [f"{p}.branch0", f"{p}.branch1.0", f"{p}.branch1.1",
+                  f"{p}.branch2.0", f"{p}.branch2.1", f"{p}.branch2.2"]
+    names += ["mixed_6a.branch0", "mixed_6a.branch1.0", "mixed_6a.branch1.1", "mixed_6a.branch1.2"]
+    for i in range(10):
+        p = f"repeat_2.{i}"
+        names += [f"{p}.branch0", f"{p}.branch1.0", f"{p}.branch1.1", f"{p}.branch1.2"]
+    names += ["mixed_7a.branch0.0", "mixed_7a.branch0.1", "mixed_7a.branch1.0", "mixed_7a.branch1.1",
+              "mixed_7a.branch2.0", "mixed_7a.branch2.1", "mixed_7a.branch2.2"]
+    for p in [f"repeat_3.{i}" for i in range(5)] + ["block8"]:
+        names += [f"{p}.branch0", f"{p}.branch1.0", f"{p}.branch1.1", f"{p}.branch1.2"]
+    return names
+
+
+def facenet_proj_convs():
+    return ([f"repeat_1.{i}.conv2d" for i in range(5)] + [f"repeat_2.{i}.conv2d" for i in range(10)]
+            + [f"repeat_3.{i}.conv2d" for i in range(5)] + ["block8.conv2d"])
+
+
+# (cout, cin, kh, kw) of every facenet conv, for the synthetic generator
+def _facenet_shapes():
+    s = {
+        "conv2d_1a": (32, 3, 3, 3), "conv2d_2a": (32, 32, 3, 3), "conv2d_2b": (64, 32, 3, 3),
+        "conv2d_3b": (80, 64, 1, 1), "conv2d_4a": (192, 80, 3, 3), "conv2d_4b": (256, 192, 3, 3),
+        "mixed_6a.branch0": (384, 256, 3, 3), "mixed_6a.branch1.0": (192, 256, 1, 1),
+        "mixed_6a.branch1.1": (192, 192, 3, 3), "mixed_6a.branch1.2": (256, 192, 3, 3),
+        "mixed_7a.branch0.0": (256, 896, 1, 1), "mixed_7a.branch0.1": (384, 256, 3, 3),
+        "mixed_7a.branch1.0": (256, 896, 1, 1), "mixed_7a.branch1.1": (256, 256, 3, 3),
+        "mixed_7a.branch2.0": (256, 896, 1, 1), "mixed_7a.branch2.1": (256, 256, 3, 3),
+        "mixed_7a.branch2.2": (256, 256, 3, 3),
+    }
+    for i in range(5):
+        p = f"repeat_1.{i}"
+        s[f"{p}.branch0"] = (32, 256, 1, 1)
+        s[f"{p}.branch1.0"] = (32, 256, 1, 1); s[f"{p}.branch1.1"] = (32, 32, 3, 3)
+        s[f"{p}.branch2.0"] = (32, 256, 1, 1); s[f"{p}.branch2.1"] = (32, 32, 3, 3)
+        s[f"{p}.branch2.2"] = (32, 32, 3, 3)
+        s[f"{p}.conv2d"] = (256, 96, 1, 1)
+    for i in range(10):
+        p = f"repeat_2.{i}"
+        s[f"{p}.branch0"] = (128, 896, 1, 1)
+        s[f"{p}.branch1.0"] = (128, 896, 1, 1); s[f"{p}.branch1.1"] = (128, 128, 1, 7)
+        s[f"{p}.branch1.2"] = (128, 128, 7, 1)
+        s[f"{p}.conv2d"] = (896, 256, 1, 1)
+    for p in [f"repeat_3.{i}" for i in range(5)] + ["block8"]:
+        s[f"{p}.branch0"] = (192, 1792, 1, 1)
+        s[f"{p}.branch1.0"] = (192, 1792, 1, 1); s[f"{p}.branch1.1"] = (192, 192, 1, 3)
+        s[f"{p}.branch1.2"] = (192, 192, 3, 1)
+        s[f"{p}.conv2d"] = (1792, 384, 1, 1)
+    return s
+
+
+MTCNN_CONVS = {  # net -> [(name, cout, cin, k, prelu_name)]
+    "pnet": [("conv1", 10, 3, 3, "prelu1"), ("conv2", 16, 10, 3, "prelu2"), ("conv3", 32, 16, 3, "prelu3"),
+             ("conv4_1", 2, 32, 1, None), ("conv4_2", 4, 32, 1, None)],
+    "rnet": [("conv1", 28, 3, 3, "prelu1"), ("conv2", 48, 28, 3, "prelu2"), ("conv3", 64, 48, 2, "prelu3")],
+    "onet": [("conv1", 32, 3, 3, "prelu1"), ("conv2", 64, 32, 3, "prelu2"), ("conv3", 64, 64, 3, "prelu3"),
+             ("conv4", 128, 64, 2, "prelu4")],
+}
+MTCNN_DENSE = {  # net -> [(name, out, (c,h,w) or in, prelu_name)]
+    "rnet": [("dense4", 128, (64, 3, 3), "prelu4"), ("dense5_1", 2, 128, None), ("dense5_2", 4, 128, None)],
+    "onet": [("dense5", 256, (128, 3, 3), "prelu5"), ("dense6_1", 2, 256, None), ("dense6_2", 4, 256, None),
+             ("dense6_3", 10, 256, None)],
+}
+
+
+# ---- packing ---------------------------------------------------------------------------------
+
+def canonical_tensors(pnet: Mapping, rnet: Mapping, onet: Mapping, facenet: Mapping) -> Dict[str, np.ndarray]:
+    """state_dicts (facenet-pytorch key layout) -> {canonical name: float32 array}."""
+    out: Dict[str, np.ndarray] = {}
+    for net, sd in (("pnet", pnet), ("rnet", rnet), ("onet", onet)):
+        for name, _co, _ci, _k, prelu in MTCNN_CONVS[net]:
+            out[f"{net}.{name}.w"] = _conv_w(sd[f"{name}.weight"])
+            out[f"{net}.{name}.b"] = _np(sd[f"{name}.bias"]).astype(np.float32)
+            if prelu:
+                out[f"{net}.{prelu}"] = _np(sd[f"{prelu}.weight"]).astype(np.float32)
+        for name, _o, shp, prelu in MTCNN_DENSE.get(net, []):
+            w = sd[f"{name}.weight"]
+            if isinstance(shp, tuple):
+                out[f"{net}.{name}.w"] = _dense_w(w, *shp)
+            else:
+                out[f"{net}.{name}.w"] = np.ascontiguousarray(_np(w).astype(np.float32).T)
+            out[f"{net}.{name}.b"] = _np(sd[f"{name}.bias"]).astype(np.float32)
+            if prelu:
+                out[f"{net}.{prelu}"] = _np(sd[f"{prelu}.weight"]).astype(np.float32)
+    for name in facenet_basic_convs():
+        out[f"facenet.{name}.w"] = _conv_w(facenet[f"{name}.conv.weight"])
+        a, b = _fold_bn(facenet, f"{name}.bn")
+        out[f"facenet.{name}.scale"] = a
+        out[f"facenet.{name}.shift"] = b
+    for name in facenet_proj_convs():
+        out[f"facenet.{name}.w"] = _conv_w(facenet[f"{name}.weight"])
+        out[f"facenet.{name}.b"] = _np(facenet[f"{name}.bias"]).astype(np.float32)
+    out["facenet.last_linear.w"] = np.ascontiguousarray(_np(facenet["last_linear.weight"]).astype(np.float32).T)
+    a, b = _fold_bn(facenet, "last_bn")
+    out["facenet.last_bn.scale"] = a
+    out["facenet.last_bn.shift"] = b
+    return out
+
+
+def pack_tensors(tensors: Mapping[str, np.ndarray]) -> bytes:
+    names = list(tensors.keys())
+    head = 16 + _ENTRY.size * len(names)
+    off = (head + 63) // 64 * 64
+    entries, blobs = [], []
+    for n in names:
+        a = np.ascontiguousarray(tensors[n], dtype=np.float32)
+        dims = list(a.shape) + [1] * (4 - a.ndim)
+        nb = a.nbytes
+        entries.append(_ENTRY.pack(n.encode()[:55], a.ndim, *dims, off, nb))
+        blobs.append((off, a.tobytes()))
+        off = (off + nb + 63) // 64 * 64
+    buf = bytearray(off)
+    buf[0:8] = MAGIC
+    buf[8:12] = struct.pack("<I", len(names))
+    p = 16
+    for e in entries:
+        buf[p:p + _ENTRY.size] = e
+        p += _ENTRY.size
+    for o, b in blobs:
+        buf[o:o + len(b)] = b
+    return bytes(buf)
+
+
+def unpack_tensors(blob: bytes) -> Dict[str, np.ndarray]:
+    assert blob[:8] == MAGIC
+    (n,) = struct.unpack_from("<I", blob, 8)
+    out = {}
+    for i in range(n):
+        name, ndim, d0, d1, d2, d3, off, nb = _ENTRY.unpack_from(blob, 16 + i * _ENTRY.size)
+        dims = [d0, d1, d2, d3][:ndim]
+        out[name.rstrip(b"\0").decode()] = np.frombuffer(blob, np.float32, nb // 4, off).reshape(dims)
+    return out
+
+
+def pack_state_dicts(pnet, rnet, onet, facenet) -> bytes:
+    return pack_tensors(canonical_tensors(pnet, rnet, onet, facenet))
+
+
+# ---- synthetic weights ---------------------------------------------------------------------
+
+# The random cascade is calibrated once (oracle/calibrate_synthetic.py, dev time) on the seeded
+# synthetic clip so it behaves like a trained one in *candidate counts*: ~0.2 % of PNet cells pass
+# thr0, about an eighth of R-Net and 40 % of O-Net candidates pass, and last_bn whitens the
+# embedding.  The result is shipped as data next to this file.
+_CAL_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "synthetic_calibration.npz")
+
+
+def _load_calibration(seed: int):
+    if os.path.exists(_CAL_FILE):
+        z = np.load(_CAL_FILE)
+        if int(z["seed"]) == seed:
+            return ({"pnet": float(z["pnet"]), "rnet": float(z["rnet"]), "onet": float(z["onet"])},
+                    z["last_bn_mean"].astype(np.float32), z["last_bn_var"].astype(np.float32))
+    return {"pnet": 0.0, "rnet": 0.0, "onet": 0.0}, None, None
+
+
+def synthetic_state_dicts(seed: int = 0, calibration: Mapping[str, float] | None = None, use_file: bool = True):
+    """Seeded random weights with facenet-pytorch's state_dict key layout and shapes."""
+    rng = np.random.default_rng(seed)
+    cal, bn_mean, bn_var = _load_calibration(seed) if use_file else ({"pnet": 0.0, "rnet": 0.0, "onet": 0.0}, None, None)
+    if calibration:
+        cal.update(calibration)
+
+    def conv(co, ci, kh, kw, gain=1.0):
+        std = gain * np.sqrt(2.0 / (ci * kh * kw))
+        return (rng.standard_normal((co, ci, kh, kw)) * std).astype(np.float32)
+
+    nets = {}
+    for net in ("pnet", "rnet", "onet"):
+        sd = {}
+        for name, co, ci, k, prelu in MTCNN_CONVS[net]:
+            sd[f"{name}.weight"] = conv(co, ci, k, k)
+            sd[f"{name}.bias"] = (rng.standard_normal(co) * 0.05).astype(np.float32)
+            if prelu:
+                sd[f"{prelu}.weight"] = rng.uniform(0.05, 0.3, co).astype(np.float32)
+        for name, o, shp, prelu in MTCNN_DENSE.get(net, []):
+            fan = int(np.prod(shp)) if isinstance(shp, tuple) else shp
+            sd[f"{name}.weight"] = (rng.standard_normal((o, fan)) * np.sqrt(2.0 / fan)).astype(np.float32)
+            sd[f"{name}.bias"] = (rng.standard_normal(o) * 0.05).astype(np.float32)
+            if prelu:
+                sd[f"{prelu}.weight"] = rng.uniform(0.05, 0.3, o).astype(np.float32)
+        # box-regression / landmark heads: keep offsets small like a trained net's
+        for name in ("conv4_2", "dense5_2", "dense6_2", "dense6_3"):
+            if f"{name}.weight" in sd:
+                sd[f"{name}.weight"] *= np.float32(0.08)
+                sd[f"{name}.bias"] *= np.float32(0.5)
+        if "dense6_3.bias" in sd:  # landmarks live in [0,1] of the box
+            sd["dense6_3.bias"] = (sd["dense6_3.bias"] + np.float32(0.5)).astype(np.float32)
+        # class head: shift the face logit by the calibrated offset
+        cls = {"pnet": "conv4_1", "rnet": "dense5_1", "onet": "dense6_1"}[net]
+        b = sd[f"{cls}.bias"].copy()
+        b[1] += np.float32(cal[net])
+        sd[f"{cls}.bias"] = b
+        nets[net] = sd
+
+    fn = {}
+    shapes = _facenet_shapes()
+    for name in facenet_basic_convs():
+        co, ci, kh, kw = shapes[name]
+        fn[f"{name}.conv.weight"] = conv(co, ci, kh, kw)
+        fn[f"{name}.bn.weight"] = rng.uniform(0.7, 1.3, co).astype(np.float32)
+        fn[f"{name}.bn.bias"] = (rng.standard_normal(co) * 0.1).astype(np.float32)
+        fn[f"{name}.bn.running_mean"] = (rng.standard_normal(co) * 0.1).astype(np.float32)
+        fn[f"{name}.bn.running_var"] = rng.uniform(0.6, 1.4, co).astype(np.float32)
+        fn[f"{name}.bn.num_batches_tracked"] = np.array(1, dtype=np.int64)
+    for name in facenet_proj_convs():
+        co, ci, kh, kw = shapes[name]
+        fn[f"{name}.weight"] = conv(co, ci, kh, kw)
+        fn[f"{name}.bias"] = (rng.standard_normal(co) * 0.05).astype(np.float32)
+    fn["last_linear.weight"] = (rng.standard_normal((512, 1792)) * np.sqrt(1.0 / 1792)).astype(np.float32)
+    fn["last_bn.weight"] = rng.uniform(0.7, 1.3, 512).astype(np.float32)
+    fn["last_bn.bias"] = (rng.standard_normal(512) * 0.1).astype(np.float32)
+    fn["last_bn.running_mean"] = (rng.standard_normal(512) * 0.1).astype(np.float32)
+    fn["last_bn.running_var"] = rng.uniform(0.6, 1.4, 512).astype(np.float32)
+    fn["last_bn.num_batches_tracked"] = np.array(1, dtype=np.int64)
+    if bn_mean is not None:
+        fn["last_bn.running_mean"] = bn_mean
+        fn["last_bn.running_var"] = bn_var
+        fn["last_bn.weight"] = np.ones(512, np.float32)
+        fn["last_bn.bias"] = np.zeros(512, np.float32)
+    return nets["pnet"], nets["rnet"], nets["onet"], fn
+
+
+def synthetic_blob(seed: int = 0, calibration: Mapping[str, float] | None = None) -> bytes:
+    return pack_state_dicts(*synthetic_state_dicts(seed, calibration))
