@@ -1,0 +1,126 @@
+/*
+ * truely_hip.h -- C ABI of libtruely_hip.so: the MI355X (gfx950) implementation of Truely's
+ * per-frame visual hot path.
+ *
+ * The reference has no FFI / plugin layer: its boundary is the Python function
+ *     run(video_path_one, video_path_two) -> int          (server/model.py:11-14)
+ * imported by the FastAPI handlers (server/server.py:35,611,856), which internally makes two
+ * library calls per sampled frame:
+ *     boxes, _ = mtcnn.detect(frame)                       (server/model.py:47)
+ *     emb = facenet_model(face_tensor)                     (server/model.py:59)
+ * followed by the cosine-drift state machine (server/model.py:60-66,86-95).
+ * Every entry point below names the reference lines it replaces.  Plain pointers and sizes only:
+ * no torch types.  All `d_*` pointers are DEVICE pointers owned by the caller (e.g. the
+ * data_ptr() of torch-ROCm tensors); `stream` is a hipStream_t passed as void*.
+ *
+ * Error convention: every function returns TRL_OK (0) or a negative trl_status; a thread-local
+ * message is available from trl_last_error().  (model.run() itself maps failures to the
+ * reference's `return 0`, server/model.py:20-34,83-88.)
+ *
+ * Threading: a context is bound to one device and one in-flight call; use one context per GPU /
+ * rank.  Calls on distinct contexts are independent.
+ */
+#ifndef TRUELY_HIP_H
+#define TRUELY_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRL_ABI_VERSION 1
+
+typedef enum {
+    TRL_OK = 0,
+    TRL_ERR_INVALID = -1,   /* bad argument / shape */
+    TRL_ERR_HIP = -2,       /* HIP runtime error (message has hipGetErrorString) */
+    TRL_ERR_WEIGHTS = -3,   /* blob malformed or tensor missing */
+    TRL_ERR_CAPACITY = -4,  /* a candidate list exceeded its configured capacity */
+    TRL_ERR_STATE = -5      /* call order (e.g. no weights loaded) */
+} trl_status;
+
+typedef struct trl_ctx trl_ctx;
+
+/* MTCNN() constructor arguments that affect detect() (facenet_pytorch MTCNN.__init__ defaults,
+ * as instantiated at server/model.py:18) plus capacities of the device-side candidate lists. */
+typedef struct {
+    int    device;          /* HIP device ordinal */
+    int    min_face_size;   /* 20 */
+    float  thr0, thr1, thr2;/* 0.6 0.7 0.7 */
+    double factor;          /* 0.709 */
+    int    cap_level;       /* max PNet cells passing thr0 per (frame, pyramid level)   [4096] */
+    int    cap_frame;       /* max candidates per frame entering R-Net                   [4096] */
+    int    max_faces;       /* max boxes returned per frame by trl_mtcnn_detect          [64]   */
+    int    pnet_mode;       /* 0 = fused PNet kernel, 1 = generic layer path (validation) */
+} trl_config;
+
+int  trl_abi_version(void);
+const char* trl_last_error(void);
+int  trl_default_config(trl_config* cfg);
+
+/* Replaces the per-call model construction at server/model.py:18-19: create once, load the
+ * packed weights (TRLW0001 blob from weights.pack_state_dicts) once, reuse for every clip. */
+int  trl_create(const trl_config* cfg, trl_ctx** out);
+int  trl_destroy(trl_ctx* ctx);
+int  trl_load_weights(trl_ctx* ctx, const void* host_blob, size_t nbytes);
+
+/* server/model.py:47  `boxes, probs = mtcnn.detect(frame)` for a batch of n frames.
+ *   d_frames : u8  [n][H][W][3]  BGR as cv2.VideoCapture.read() yields (model.py:43)
+ *   d_boxes  : f32 [n][max_faces][4]   x1,y1,x2,y2, largest area first (select_largest=True)
+ *   d_probs  : f32 [n][max_faces]
+ *   d_counts : i32 [n]                 number of faces (0 <=> detect() returned None) */
+int  trl_mtcnn_detect(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
+                      float* d_boxes, float* d_probs, int32_t* d_counts, void* stream);
+
+/* server/model.py:59  `facenet_model(face_tensor)`:  InceptionResnetV1(...).eval() forward.
+ *   d_faces : f32 [n][h][w][3] NHWC, already scaled as model.py:58 does (to_tensor: /255)
+ *   d_emb   : f32 [n][512], L2-normalised */
+int  trl_facenet_embed(trl_ctx* ctx, const float* d_faces, int n, int h, int w, float* d_emb, void* stream);
+
+/* server/model.py:47-59 fused for a batch of sampled frames: detect, take boxes[0], int-cast +
+ * clamp (model.py:49-53), crop, cv2.resize(...,(80,80)) (model.py:55-57), to_tensor (model.py:58),
+ * embed (model.py:59).
+ *   d_box   : f32 [n][4]   boxes[0] (zeros if none)
+ *   d_prob  : f32 [n]
+ *   d_rect  : i32 [n][4]   clamped integer crop rectangle x0,y0,x1,y1
+ *   d_valid : u8  [n]      1 iff an embedding was produced for the frame (model.py:48,54,56)
+ *   d_emb   : f32 [n][512] (zero rows where !valid) */
+int  trl_detect_embed(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
+                      float* d_box, float* d_prob, int32_t* d_rect, uint8_t* d_valid, float* d_emb,
+                      void* stream);
+
+/* server/model.py:60-66,70,75,86-95: cosine similarity against the last embedded frame, the
+ * run-length counter, and the 0..100 score.  n = number of sampled frames (in time order),
+ * frame_count = frames decoded, fps as int(cap.get(CAP_PROP_FPS)) (model.py:28).
+ *   d_sims   : f32 [n]  (2.0 where no comparison happened)        may be NULL
+ *   d_flags  : u8  [n]  1 where the frame was counted "AI detected" (model.py:66)  may be NULL
+ *   d_result : i32 [4]  {score, final run length, hits, total sampled frames} */
+int  trl_drift_score(trl_ctx* ctx, const float* d_emb, const uint8_t* d_valid, int n,
+                     long long frame_count, int fps, float* d_sims, uint8_t* d_flags,
+                     int32_t* d_result, void* stream);
+
+/* ---- inspection hooks used by the parity tests (stage-by-stage vs the oracle) ------------- */
+/* Boxes of one frame after cascade stage 1/2/3 of the LAST trl_mtcnn_detect / trl_detect_embed
+ * call (host output, rows of 5: x1,y1,x2,y2,score).  Returns the count in *n_out. */
+int  trl_debug_stage_boxes(trl_ctx* ctx, int stage, int frame, float* h_boxes, int max_rows, int* n_out);
+/* Per-level PNet candidate / kept counts of one frame (host output, up to 32 levels each). */
+int  trl_debug_level_counts(trl_ctx* ctx, int frame, int32_t* h_cand, int32_t* h_keep, int* n_levels);
+/* PNet on one pyramid level of frame 0: face-prob map and regression map (device outputs). */
+int  trl_debug_pnet_level(trl_ctx* ctx, const uint8_t* d_frame, int H, int W, int level,
+                          float* d_prob, float* d_reg, int* oh, int* ow, void* stream);
+/* R-Net / O-Net on prepared crops: d_crops f32 [n][S][S][3]; d_out f32 [n][6] / [n][16]
+ * = {logit0, logit1, reg[4], (landmarks[10])}. */
+int  trl_debug_rnet(trl_ctx* ctx, const float* d_crops, int n, float* d_out, void* stream);
+int  trl_debug_onet(trl_ctx* ctx, const float* d_crops, int n, float* d_out, void* stream);
+/* model.py:55-58 alone: crop rect (x0,y0,x1,y1 per frame, i32) -> f32 [n][80][80][3] in [0,1] */
+int  trl_debug_crop_resize(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
+                           const int32_t* d_rect, const uint8_t* d_valid, float* d_faces, void* stream);
+/* Time (ms, HIP events on the call's stream) spent in the dominant kernels during the last
+ * trl_detect_embed call: out[0]=PNet kernel(s), out[1]=whole call, out[2]=#PNet launches. */
+int  trl_debug_timings(trl_ctx* ctx, float* out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

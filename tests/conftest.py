@@ -1,0 +1,54 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import truely_amd  # noqa: E402  (import shim for the hyphenated package directory)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def state_dicts():
+    return truely_amd.weights.synthetic_state_dicts(0)
+
+
+@pytest.fixture(scope="session")
+def blob(state_dicts):
+    return truely_amd.weights.pack_state_dicts(*state_dicts)
+
+
+@pytest.fixture(scope="session")
+def oracle(blob):
+    from oracle.oracle import Oracle
+    return Oracle(blob)
+
+
+@pytest.fixture(scope="session")
+def engine(blob):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from truely_amd.engine import Engine
+    return Engine(blob)
+
+
+@pytest.fixture(scope="session")
+def engine_generic(blob):
+    """Same weights, PNet through the generic layer kernels (validation path)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from truely_amd.engine import Engine
+    return Engine(blob, pnet_mode=1)
+
+
+def frames_small(n=6, H=180, W=320, seed=3):
+    return truely_amd.synthetic.synthetic_frames(n, H, W, seed=seed)

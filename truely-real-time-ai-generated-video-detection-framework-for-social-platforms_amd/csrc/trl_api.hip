@@ -1,0 +1,343 @@
+// trl_api.hip -- C ABI of libtruely_hip.so (see include/truely_hip.h for the contract and the
+// reference lines each entry point replaces).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "trl_ctx.h"
+
+static thread_local char g_err[512] = "";
+void trl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int trl_abi_version(void) { return TRL_ABI_VERSION; }
+const char* trl_last_error(void) { return g_err; }
+
+int trl_default_config(trl_config* cfg) {
+    if (!cfg) return TRL_ERR_INVALID;
+    cfg->device = 0;
+    cfg->min_face_size = 20;           // facenet_pytorch MTCNN.__init__ defaults (server/model.py:18)
+    cfg->thr0 = 0.6f; cfg->thr1 = 0.7f; cfg->thr2 = 0.7f;
+    cfg->factor = 0.709;
+    cfg->cap_level = 2048;
+    cfg->cap_frame = 2048;
+    cfg->max_faces = 64;
+    cfg->pnet_mode = 0;
+    return TRL_OK;
+}
+
+int trl_create(const trl_config* cfg, trl_ctx** out) {
+    if (!cfg || !out) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
+    if (cfg->cap_level < 64 || cfg->cap_level > 3072 || cfg->cap_frame < 64 || cfg->cap_frame > 3072 || (cfg->cap_level & 3) ||
+        (cfg->cap_frame & 3) || cfg->min_face_size < 12 || cfg->max_faces < 1 || !(cfg->factor > 0.1 && cfg->factor < 0.99)) {
+        trl_set_error("bad trl_config (capacities must be multiples of 4 in [64,3072], min_face_size >= 12)");
+        return TRL_ERR_INVALID;
+    }
+    TRL_HIP(hipSetDevice(cfg->device));
+    trl_ctx* c = new trl_ctx();
+    c->cfg = *cfg;
+    if (hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess) { delete c; trl_set_error("hipHostMalloc failed"); return TRL_ERR_HIP; }
+    memset(c->h_pinned, 0, 256);
+    hipEventCreate(&c->ev_call0);
+    hipEventCreate(&c->ev_call1);
+    *out = c;
+    return TRL_OK;
+}
+
+int trl_destroy(trl_ctx* c) {
+    if (!c) return TRL_OK;
+    hipSetDevice(c->cfg.device);
+    hipDeviceSynchronize();
+    if (c->wdev) hipFree(c->wdev);
+    if (c->arena.base) hipFree(c->arena.base);
+    if (c->scratch.base) hipFree(c->scratch.base);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->ev_call0) hipEventDestroy(c->ev_call0);
+    if (c->ev_call1) hipEventDestroy(c->ev_call1);
+    for (auto& e : c->pnet_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete c;
+    return TRL_OK;
+}
+
+}  // extern "C"
+
+// ---- weights ---------------------------------------------------------------------------------------
+namespace {
+struct Entry {
+    char name[56];
+    uint32_t ndim;
+    uint32_t dims[4];
+    uint64_t offset;
+    uint64_t nbytes;
+};
+static_assert(sizeof(Entry) == 96, "TRLW entry layout");
+}  // namespace
+
+const DevW* trl_w(trl_ctx* c, const std::string& name) {
+    auto it = c->W.find(name);
+    if (it == c->W.end()) { trl_set_error("weight matrix '%s' not loaded", name.c_str()); return nullptr; }
+    return &it->second;
+}
+const DevV* trl_v(trl_ctx* c, const std::string& name) {
+    auto it = c->V.find(name);
+    if (it == c->V.end()) { trl_set_error("weight vector '%s' not loaded", name.c_str()); return nullptr; }
+    return &it->second;
+}
+
+int trl_ensure(trl_ctx* c, Arena& a, size_t bytes) {
+    if (bytes <= a.cap) return TRL_OK;
+    // Growing frees the old block, so it is only called while nothing allocated from `a` is live:
+    // at the start of a call (arena) or between cascade stages (scratch).
+    const size_t ncap = bytes + (bytes >> 3) + (32u << 20);
+    TRL_HIP(hipDeviceSynchronize());
+    if (a.base) { TRL_HIP(hipFree(a.base)); a.base = nullptr; a.cap = 0; }
+    TRL_HIP(hipMalloc((void**)&a.base, ncap));
+    a.cap = ncap;
+    a.off = 0;
+    (void)c;
+    return TRL_OK;
+}
+
+extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
+    if (!c || !blob) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
+    const uint8_t* b = (const uint8_t*)blob;
+    if (nbytes < 16 || memcmp(b, "TRLW0001", 8) != 0) { trl_set_error("bad weights blob magic"); return TRL_ERR_WEIGHTS; }
+    uint32_t nt;
+    memcpy(&nt, b + 8, 4);
+    if (16 + (size_t)nt * sizeof(Entry) > nbytes) { trl_set_error("truncated weights blob"); return TRL_ERR_WEIGHTS; }
+    const Entry* ent = (const Entry*)(b + 16);
+    TRL_HIP(hipSetDevice(c->cfg.device));
+
+    struct Pending { std::string name; bool mat; int K, Cout, Kpad, ld, n; size_t off; const float* src; };
+    std::vector<Pending> items;
+    size_t total = 0;
+    auto add_mat = [&](const std::string& name, int K, int Cout, const float* src) {
+        Pending p; p.name = name; p.mat = true; p.K = K; p.Cout = Cout; p.Kpad = (K + 15) / 16 * 16; p.ld = (Cout + 31) / 32 * 32;
+        p.n = 0; p.src = src; p.off = total;
+        total += ((size_t)p.Kpad * p.ld * 4 + 255) & ~(size_t)255;
+        items.push_back(p);
+    };
+    auto add_vec = [&](const std::string& name, int n, const float* src) {
+        Pending p; p.name = name; p.mat = false; p.K = p.Cout = p.Kpad = p.ld = 0; p.n = n; p.src = src; p.off = total;
+        total += ((size_t)((n + 127) / 128 * 128) * 4 + 255) & ~(size_t)255;
+        items.push_back(p);
+    };
+    std::unordered_map<std::string, const Entry*> idx;
+    for (uint32_t i = 0; i < nt; i++) {
+        const Entry& e = ent[i];
+        if (e.offset + e.nbytes > nbytes) { trl_set_error("tensor out of blob bounds"); return TRL_ERR_WEIGHTS; }
+        std::string name(e.name, strnlen(e.name, 56));
+        idx[name] = &e;
+        const float* src = (const float*)(b + e.offset);
+        if (e.ndim == 2) add_mat(name, (int)e.dims[0], (int)e.dims[1], src);
+        else if (e.ndim == 1) add_vec(name, (int)e.dims[0], src);
+    }
+    // merged heads: the 1x1 class and regression (and landmark) convs share their input, so they run as
+    // one [K][6] / [K][16] matrix; each output column is still its own fmaf chain (bit-identical).
+    std::vector<std::vector<float>> keep_alive;
+    auto merge_heads = [&](const std::string& net, const std::vector<std::string>& parts) -> int {
+        int K = -1, tot = 0;
+        for (auto& p : parts) {
+            auto it = idx.find(net + "." + p + ".w");
+            auto ib = idx.find(net + "." + p + ".b");
+            if (it == idx.end() || ib == idx.end()) { trl_set_error("missing head %s.%s", net.c_str(), p.c_str()); return TRL_ERR_WEIGHTS; }
+            if (K < 0) K = (int)it->second->dims[0];
+            tot += (int)it->second->dims[1];
+        }
+        keep_alive.emplace_back((size_t)K * tot);
+        std::vector<float>& w = keep_alive.back();
+        keep_alive.emplace_back((size_t)tot);
+        std::vector<float>& bias = keep_alive[keep_alive.size() - 1];
+        std::vector<float>& wm = keep_alive[keep_alive.size() - 2];
+        (void)w;
+        int col = 0;
+        for (auto& p : parts) {
+            const Entry* e = idx[net + "." + p + ".w"];
+            const Entry* eb = idx[net + "." + p + ".b"];
+            const float* src = (const float*)(b + e->offset);
+            const float* sb = (const float*)(b + eb->offset);
+            const int co = (int)e->dims[1];
+            for (int k = 0; k < K; k++) for (int j = 0; j < co; j++) wm[(size_t)k * tot + col + j] = src[(size_t)k * co + j];
+            for (int j = 0; j < co; j++) bias[col + j] = sb[j];
+            col += co;
+        }
+        add_mat(net + ".heads.w", K, tot, wm.data());
+        add_vec(net + ".heads.b", tot, bias.data());
+        return TRL_OK;
+    };
+    keep_alive.reserve(16);
+    TRL_CHECK(merge_heads("pnet", {"conv4_1", "conv4_2"}));
+    TRL_CHECK(merge_heads("rnet", {"dense5_1", "dense5_2"}));
+    TRL_CHECK(merge_heads("onet", {"dense6_1", "dense6_2", "dense6_3"}));
+
+    std::vector<char> host(total, 0);
+    for (auto& p : items) {
+        float* dst = (float*)(host.data() + p.off);
+        if (p.mat) { for (int k = 0; k < p.K; k++) memcpy(dst + (size_t)k * p.ld, p.src + (size_t)k * p.Cout, (size_t)p.Cout * 4); }
+        else memcpy(dst, p.src, (size_t)p.n * 4);
+    }
+    if (c->wdev) { TRL_HIP(hipDeviceSynchronize()); TRL_HIP(hipFree(c->wdev)); c->wdev = nullptr; }
+    TRL_HIP(hipMalloc((void**)&c->wdev, total));
+    TRL_HIP(hipMemcpy(c->wdev, host.data(), total, hipMemcpyHostToDevice));
+    c->wbytes = total;
+    c->W.clear(); c->V.clear();
+    for (auto& p : items) {
+        if (p.mat) { DevW w; w.p = (float*)(c->wdev + p.off); w.K = p.K; w.Cout = p.Cout; w.Kpad = p.Kpad; w.ld = p.ld; c->W[p.name] = w; }
+        else { DevV v; v.p = (float*)(c->wdev + p.off); v.n = p.n; c->V[p.name] = v; }
+    }
+
+    TRL_CHECK(trl_pnet_prepare(c));
+    c->have_weights = true;
+    return TRL_OK;
+}
+
+// ---- hot path ---------------------------------------------------------------------------------------
+static int check_call(trl_ctx* c, const void* frames, int n, int H, int W) {
+    if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
+    if (!c->have_weights) { trl_set_error("trl_load_weights has not been called"); return TRL_ERR_STATE; }
+    if (!frames || n <= 0 || H < 12 || W < 12 || H > 16384 || W > 16384) { trl_set_error("bad frame batch n=%d H=%d W=%d", n, H, W); return TRL_ERR_INVALID; }
+    return TRL_OK;
+}
+
+static void collect_timings(trl_ctx* c) {
+    float call_ms = 0.f, pnet_ms = 0.f;
+    hipEventElapsedTime(&call_ms, c->ev_call0, c->ev_call1);
+    for (int i = 0; i < c->pnet_ev_used; i++) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, c->pnet_ev[i].first, c->pnet_ev[i].second) == hipSuccess) pnet_ms += t;
+    }
+    c->last_ms[0] = pnet_ms; c->last_ms[1] = call_ms; c->last_ms[2] = (float)c->pnet_ev_used;
+}
+
+extern "C" {
+
+int trl_mtcnn_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, int32_t* d_counts,
+                     void* stream) {
+    TRL_CHECK(check_call(c, d_frames, n, H, W));
+    if (!d_boxes || !d_probs || !d_counts) { trl_set_error("null output"); return TRL_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    TRL_HIP(hipEventRecord(c->ev_call0, s));
+    TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
+    // scratch for the model.py-only outputs
+    float* box0 = (float*)c->arena.alloc((size_t)n * 16); float* prob0 = (float*)c->arena.alloc((size_t)n * 4);
+    int32_t* rect = (int32_t*)c->arena.alloc((size_t)n * 16); uint8_t* valid = (uint8_t*)c->arena.alloc((size_t)n);
+    if (!valid) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
+    TRL_HIP(hipMemsetAsync(d_boxes, 0, (size_t)n * c->cfg.max_faces * 16, s));
+    TRL_HIP(hipMemsetAsync(d_probs, 0, (size_t)n * c->cfg.max_faces * 4, s));
+    TRL_HIP(hipEventRecord(c->ev_call1, s));
+    TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, d_boxes, d_probs, d_counts, box0, prob0, rect, valid, s));
+    collect_timings(c);
+    return TRL_OK;
+}
+
+int trl_facenet_embed(trl_ctx* c, const float* d_faces, int n, int h, int w, float* d_emb, void* stream) {
+    if (!c || !c->have_weights) { trl_set_error("context without weights"); return TRL_ERR_STATE; }
+    if (!d_faces || !d_emb || n <= 0 || h < 75 || w < 75) { trl_set_error("bad face batch n=%d %dx%d (min 75x75)", n, h, w); return TRL_ERR_INVALID; }
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    c->scratch.reset();
+    TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * ((size_t)h * w * 110 + 400000) * 4 + (8u << 20)));
+    return trl_run_facenet(c, d_faces, n, h, w, nullptr, d_emb, (hipStream_t)stream);
+}
+
+int trl_detect_embed(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
+                     uint8_t* d_valid, float* d_emb, void* stream) {
+    TRL_CHECK(check_call(c, d_frames, n, H, W));
+    if (!d_box || !d_prob || !d_rect || !d_valid || !d_emb) { trl_set_error("null output"); return TRL_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    TRL_HIP(hipEventRecord(c->ev_call0, s));
+    TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
+    TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, s));
+    c->scratch.reset();
+    TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * (80 * 80 * 110 + 400000) * 4 + (8u << 20)));
+    float* faces = (float*)c->scratch.alloc((size_t)n * 80 * 80 * 3 * 4);
+    if (!faces) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
+    TRL_CHECK(trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, faces, s));
+    TRL_CHECK(trl_run_facenet(c, faces, n, 80, 80, d_valid, d_emb, s));
+    TRL_HIP(hipEventRecord(c->ev_call1, s));
+    TRL_HIP(hipStreamSynchronize(s));
+    collect_timings(c);
+    return TRL_OK;
+}
+
+int trl_drift_score(trl_ctx* c, const float* d_emb, const uint8_t* d_valid, int n, long long frame_count, int fps, float* d_sims,
+                    uint8_t* d_flags, int32_t* d_result, void* stream) {
+    if (!c || !d_emb || !d_valid || !d_result || n < 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    return trl_launch_drift(d_emb, d_valid, n, frame_count, fps, d_sims, d_flags, d_result, (hipStream_t)stream);
+}
+
+// ---- inspection hooks ----------------------------------------------------------------------------------
+int trl_debug_stage_boxes(trl_ctx* c, int stage, int frame, float* h_boxes, int max_rows, int* n_out) {
+    if (!c || !c->cb.n1 || frame < 0 || frame >= c->cb.n || stage < 1 || stage > 3) { trl_set_error("no cascade state"); return TRL_ERR_STATE; }
+    const int32_t* cnt = stage == 1 ? c->cb.n1 : (stage == 2 ? c->cb.n2 : c->cb.n3);
+    const float* src = stage == 1 ? c->cb.s1_box : (stage == 2 ? c->cb.s2_box : c->cb.s3_box);
+    int32_t k = 0;
+    TRL_HIP(hipDeviceSynchronize());
+    TRL_HIP(hipMemcpy(&k, cnt + frame, 4, hipMemcpyDeviceToHost));
+    *n_out = k;
+    const int m = k < max_rows ? k : max_rows;
+    if (m > 0) TRL_HIP(hipMemcpy(h_boxes, src + (size_t)frame * c->cfg.cap_frame * 5, (size_t)m * 20, hipMemcpyDeviceToHost));
+    return TRL_OK;
+}
+
+int trl_debug_level_counts(trl_ctx* c, int frame, int32_t* h_cand, int32_t* h_keep, int* n_levels) {
+    if (!c || !c->cb.lvl_cnt || frame < 0 || frame >= c->cb.n) { trl_set_error("no cascade state"); return TRL_ERR_STATE; }
+    TRL_HIP(hipDeviceSynchronize());
+    const int L = c->cb.L;
+    TRL_HIP(hipMemcpy(h_cand, c->cb.lvl_cnt + (size_t)frame * L, (size_t)L * 4, hipMemcpyDeviceToHost));
+    TRL_HIP(hipMemcpy(h_keep, c->cb.lvl_keep_cnt + (size_t)frame * L, (size_t)L * 4, hipMemcpyDeviceToHost));
+    *n_levels = L;
+    return TRL_OK;
+}
+
+int trl_debug_pnet_level(trl_ctx* c, const uint8_t* d_frame, int H, int W, int level, float* d_prob, float* d_reg, int* oh, int* ow,
+                         void* stream) {
+    TRL_CHECK(check_call(c, d_frame, 1, H, W));
+    hipStream_t s = (hipStream_t)stream;
+    const int L = trl_compute_levels(c, H, W);
+    if (level < 0 || level >= L) { trl_set_error("level %d out of range (%d levels)", level, L); return TRL_ERR_INVALID; }
+    const LevelGeom& g = c->lv[level];
+    c->scratch.reset();
+    TRL_CHECK(trl_ensure(c, c->scratch, trl_pnet_generic_bytes(1, g.h, g.w) + (size_t)g.h * g.w * 12 + (size_t)g.oh * g.ow * 24 + (4u << 20)));
+    float* lvl = (float*)c->scratch.alloc((size_t)g.h * g.w * 12);
+    float* heads = (float*)c->scratch.alloc((size_t)g.oh * g.ow * 24);
+    TRL_CHECK(trl_launch_area_level(d_frame, 1, H, W, g.h, g.w, lvl, s));
+    TRL_CHECK(trl_run_pnet_generic(c, lvl, 1, g.h, g.w, heads, s));
+    TRL_CHECK(trl_launch_heads_to_maps(heads, g.oh * g.ow, d_prob, d_reg, s));
+    *oh = g.oh; *ow = g.ow;
+    TRL_HIP(hipStreamSynchronize(s));
+    return TRL_OK;
+}
+
+int trl_debug_rnet(trl_ctx* c, const float* d_crops, int n, float* d_out, void* stream) {
+    if (!c || !c->have_weights || !d_crops || !d_out || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    c->scratch.reset();
+    TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * 100 * 1024 + (4u << 20)));
+    return trl_run_rnet(c, d_crops, n, d_out, (hipStream_t)stream);
+}
+int trl_debug_onet(trl_ctx* c, const float* d_crops, int n, float* d_out, void* stream) {
+    if (!c || !c->have_weights || !d_crops || !d_out || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    c->scratch.reset();
+    TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * 640 * 1024 + (4u << 20)));
+    return trl_run_onet(c, d_crops, n, d_out, (hipStream_t)stream);
+}
+int trl_debug_crop_resize(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid,
+                          float* d_faces, void* stream) {
+    if (!c || !d_frames || !d_rect || !d_valid || !d_faces || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    return trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, d_faces, (hipStream_t)stream);
+}
+int trl_debug_timings(trl_ctx* c, float* out3) {
+    if (!c || !out3) return TRL_ERR_INVALID;
+    out3[0] = c->last_ms[0]; out3[1] = c->last_ms[1]; out3[2] = c->last_ms[2];
+    return TRL_OK;
+}
+
+}  // extern "C"

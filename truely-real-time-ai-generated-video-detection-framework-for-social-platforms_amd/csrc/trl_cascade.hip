@@ -1,0 +1,773 @@
+// trl_cascade.hip -- the data-dependent part of MTCNN.detect on the device (gfx950).
+//
+// Restates facenet_pytorch 2.6.0 utils/detect_face.py::detect_face + MTCNN.detect
+// (select_largest=True) as called at server/model.py:47, and model.py:49-58 (int cast, clamp,
+// crop, cv2.resize INTER_LINEAR u8, to_tensor).  Everything stays on the GPU; candidates live in
+// fixed-capacity per-frame lists.  One workgroup owns one (frame, level) or one frame segment:
+//   sort   : bitonic sort in LDS on a 64-bit key  (~score | tie-break index) -> exactly the order of
+//            a stable descending sort, so results do not depend on the order candidates were
+//            appended by the PNet kernel's atomics;
+//   NMS    : greedy suppression in sorted order, all lanes test one kept box against the rest;
+//   compact: ordered compaction by block scan, so list order equals the reference's `pick` order.
+// All float expressions follow the reference's operation order (one rounding per op,
+// -ffp-contract=off), so boxes / keep masks are bit-identical to the oracle.
+#include "trl_ctx.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t f2ord(float f) {   // ascending-order preserving map
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ---- block primitives ------------------------------------------------------------------------
+__device__ void block_bitonic(uint64_t* key, uint32_t* id, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < P; t += blockDim.x) {
+                const int u = t ^ j;
+                if (u > t) {
+                    const bool up = ((t & k) == 0);
+                    const uint64_t a = key[t], b = key[u];
+                    if ((a > b) == up) {
+                        key[t] = b; key[u] = a;
+                        const uint32_t ia = id[t]; id[t] = id[u]; id[u] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+__device__ __forceinline__ int next_pow2(int n) {
+    int p = 2;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// Greedy NMS over boxes already in descending-score order.  MIN_MODE = facenet_pytorch
+// nms_numpy(..., 'Min') (+1 areas, inter/min(area), keep o <= thr); otherwise torchvision nms
+// (inter/(a_i+a_j-inter) > thr suppresses).  keep[] receives positions in pick order.
+template <bool MIN_MODE>
+__device__ int block_nms(const float4* box, const float* area, int n, float thr, uint8_t* sup, int* keep, int* nkeep) {
+    for (int t = threadIdx.x; t < n; t += blockDim.x) sup[t] = 0;
+    if (threadIdx.x == 0) *nkeep = 0;
+    __syncthreads();
+    for (int i = 0; i < n; i++) {
+        if (sup[i]) continue;   // block-uniform: sup[i] is final once all earlier kept boxes were applied
+        if (threadIdx.x == 0) { keep[*nkeep] = i; *nkeep = *nkeep + 1; }
+        const float4 bi = box[i];
+        const float ai = area[i];
+        for (int j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
+            if (sup[j]) continue;
+            const float4 bj = box[j];
+            const float xx1 = bi.x > bj.x ? bi.x : bj.x;
+            const float yy1 = bi.y > bj.y ? bi.y : bj.y;
+            const float xx2 = bi.z < bj.z ? bi.z : bj.z;
+            const float yy2 = bi.w < bj.w ? bi.w : bj.w;
+            if (MIN_MODE) {
+                float w = xx2 - xx1 + 1.f; w = w > 0.f ? w : 0.f;
+                float h = yy2 - yy1 + 1.f; h = h > 0.f ? h : 0.f;
+                const float inter = w * h;
+                const float mn = ai < area[j] ? ai : area[j];
+                const float o = inter / mn;
+                if (!(o <= thr)) sup[j] = 1;
+            } else {
+                float w = xx2 - xx1; w = w > 0.f ? w : 0.f;
+                float h = yy2 - yy1; h = h > 0.f ? h : 0.f;
+                const float inter = w * h;
+                const float ovr = inter / (ai + area[j] - inter);
+                if (ovr > thr) sup[j] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    return *nkeep;
+}
+
+// exclusive scan of 0/1 flags (n <= capacity), 256 threads; returns total, pos[] = output slot
+__device__ int block_compact_positions(const uint8_t* flag, int n, int* pos, int* part /*[257]*/) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int per = (n + T - 1) / T;
+    const int b = tid * per, e = (b + per < n) ? b + per : n;
+    int cnt = 0;
+    for (int i = b; i < e; i++) cnt += flag[i];
+    part[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < T; i++) { const int v = part[i]; part[i] = run; run += v; }
+        part[T] = run;
+    }
+    __syncthreads();
+    int o = part[tid];
+    for (int i = b; i < e; i++) { pos[i] = o; o += flag[i]; }
+    __syncthreads();
+    return part[T];
+}
+
+struct Smem {   // carve the dynamic LDS for capacity `cap`
+    uint64_t* key; uint32_t* id; float4* box; float* area; float* aux; int* keep; int* pos; uint8_t* sup; uint8_t* flg;
+    int* part; int* scal;
+    __device__ Smem(unsigned char* base, int cap) {
+        key = (uint64_t*)base;                 // 8
+        box = (float4*)(key + cap);            // 16
+        id = (uint32_t*)(box + cap);           // 4
+        area = (float*)(id + cap);             // 4
+        aux = area + cap;                      // 4
+        keep = (int*)(aux + cap);              // 4
+        pos = keep + cap;                      // 4
+        part = pos + cap;                      // 260 ints
+        scal = part + 260;                     // 8 ints
+        sup = (uint8_t*)(scal + 8);            // 1
+        flg = sup + cap;                       // 1
+    }
+    static size_t bytes(int cap) { return (size_t)cap * 46 + 268 * 4 + 64; }
+};
+
+// rerec() of one box
+__device__ __forceinline__ void rerec1(float& x1, float& y1, float& x2, float& y2) {
+    const float h = y2 - y1, w = x2 - x1;
+    const float l = w > h ? w : h;
+    x1 = x1 + w * 0.5f - l * 0.5f;
+    y1 = y1 + h * 0.5f - l * 0.5f;
+    x2 = x1 + l;
+    y2 = y1 + l;
+}
+// pad(): trunc, clamp.  ok = the reference's `ey > y-1 and ex > x-1`
+__device__ __forceinline__ bool pad1(float x1, float y1, float x2, float y2, int W, int H, int& y, int& ey, int& x, int& ex) {
+    const int bx = (int)truncf(x1), by = (int)truncf(y1), bex = (int)truncf(x2), bey = (int)truncf(y2);
+    x = bx < 1 ? 1 : bx;
+    y = by < 1 ? 1 : by;
+    ex = bex > W ? W : bex;
+    ey = bey > H ? H : bey;
+    return (ey > y - 1) && (ex > x - 1);
+}
+
+// ---- imresample (F.interpolate mode="area") of whole frames to one pyramid level --------------
+__global__ void k_area_level(const uint8_t* __restrict__ frames, int nf, int H, int W, int h, int w, float* __restrict__ out) {
+    const size_t total = (size_t)nf * h * w;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % w);
+        const int oy = (int)((idx / w) % h);
+        const int f = (int)(idx / ((size_t)w * h));
+        const int ys = (int)(((long long)oy * H) / h), ye = (int)((((long long)oy + 1) * H + h - 1) / h);
+        const int xs = (int)(((long long)ox * W) / w), xe = (int)((((long long)ox + 1) * W + w - 1) / w);
+        unsigned s0 = 0, s1 = 0, s2 = 0;
+        const uint8_t* fp = frames + (size_t)f * H * W * 3;
+        for (int y = ys; y < ye; y++) {
+            const uint8_t* p = fp + ((size_t)y * W + xs) * 3;
+            for (int x = xs; x < xe; x++, p += 3) { s0 += p[0]; s1 += p[1]; s2 += p[2]; }
+        }
+        const float kh = (float)(ye - ys), kw = (float)(xe - xs);
+        float* o = out + idx * 3;
+        o[0] = ((float)s0 / kh / kw - 127.5f) * 0.0078125f;
+        o[1] = ((float)s1 / kh / kw - 127.5f) * 0.0078125f;
+        o[2] = ((float)s2 / kh / kw - 127.5f) * 0.0078125f;
+    }
+}
+
+// generateBoundingBox on the generic path: heads [nf][oh][ow][6] -> candidate records
+__global__ void k_pnet_collect(const float* __restrict__ heads, int nf, int f0, int oh, int ow, float scale, float thr,
+                               int L, int l, int cap, int32_t* __restrict__ lvl_cnt, Cand* __restrict__ lvl_rec,
+                               int32_t* __restrict__ flags) {
+    const size_t total = (size_t)nf * oh * ow;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const float* hd = heads + idx * 6;
+        const float p = trl_softmax2_p1(hd[0], hd[1]);
+        if (!(p >= thr)) continue;
+        const int cell = (int)(idx % ((size_t)oh * ow));
+        const int f = f0 + (int)(idx / ((size_t)oh * ow));
+        const int y = cell / ow, x = cell - y * ow;
+        const int slot = atomicAdd(&lvl_cnt[f * L + l], 1);
+        if (slot >= cap) { flags[0] = 1; continue; }
+        Cand c;
+        c.x1 = floorf((2.f * (float)x + 1.f) / scale);
+        c.y1 = floorf((2.f * (float)y + 1.f) / scale);
+        c.x2 = floorf((2.f * (float)x + 12.f) / scale);
+        c.y2 = floorf((2.f * (float)y + 12.f) / scale);
+        c.score = p;
+        c.r0 = hd[2]; c.r1 = hd[3]; c.r2 = hd[4]; c.r3 = hd[5];
+        c.cell = cell;
+        lvl_rec[((size_t)f * L + l) * cap + slot] = c;
+    }
+}
+
+__global__ void k_heads_to_maps(const float* __restrict__ heads, int cells, float* __restrict__ prob, float* __restrict__ reg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const float* hd = heads + (size_t)i * 6;
+    prob[i] = trl_softmax2_p1(hd[0], hd[1]);
+    reg[4 * i + 0] = hd[2]; reg[4 * i + 1] = hd[3]; reg[4 * i + 2] = hd[4]; reg[4 * i + 3] = hd[5];
+}
+
+// ---- stage 1a: per (frame, level) batched_nms(0.5) ------------------------------------------
+__global__ __launch_bounds__(256) void k_nms_level(int L, int cap, const int32_t* __restrict__ lvl_cnt, const Cand* __restrict__ lvl_rec,
+                                                   int32_t* __restrict__ keep_cnt, int32_t* __restrict__ keep_idx,
+                                                   int32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem S(smem_raw, cap);
+    const int seg = blockIdx.x;
+    int cnt = lvl_cnt[seg];
+    if (cnt > cap) { cnt = cap; if (threadIdx.x == 0) flags[0] = 1; }
+    if (cnt == 0) { if (threadIdx.x == 0) keep_cnt[seg] = 0; return; }
+    const Cand* recs = lvl_rec + (size_t)seg * cap;
+    const int P = next_pow2(cnt);
+    for (int t = threadIdx.x; t < P; t += blockDim.x) {
+        S.key[t] = t < cnt ? (((uint64_t)(~f2ord(recs[t].score))) << 32) | (uint32_t)recs[t].cell : ~0ull;
+        S.id[t] = t;
+    }
+    __syncthreads();
+    block_bitonic(S.key, S.id, P);
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+        const Cand& c = recs[S.id[t]];
+        S.box[t] = make_float4(c.x1, c.y1, c.x2, c.y2);
+        S.area[t] = (c.x2 - c.x1) * (c.y2 - c.y1);
+    }
+    __syncthreads();
+    const int nk = block_nms<false>(S.box, S.area, cnt, 0.5f, S.sup, S.keep, S.scal);
+    for (int r = threadIdx.x; r < nk; r += blockDim.x) keep_idx[(size_t)seg * cap + r] = (int)S.id[S.keep[r]];
+    if (threadIdx.x == 0) keep_cnt[seg] = nk;
+}
+
+// ---- stage 1b: per frame batched_nms(0.7) over all levels, regress, rerec ----------------------
+__global__ __launch_bounds__(256) void k_nms_frame(int L, int cap, int capF, int W, int H, const Cand* __restrict__ lvl_rec,
+                                                   const int32_t* __restrict__ keep_cnt, const int32_t* __restrict__ keep_idx,
+                                                   int32_t* __restrict__ n1, float* __restrict__ s1_box, int32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem S(smem_raw, capF);
+    __shared__ int offs[33];
+    const int f = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int l = 0; l < L; l++) { offs[l] = run; run += keep_cnt[f * L + l]; }
+        offs[L] = run;
+    }
+    __syncthreads();
+    int total = offs[L];
+    if (total > capF) { total = capF; if (threadIdx.x == 0) flags[1] = 1; }
+    if (total == 0) { if (threadIdx.x == 0) n1[f] = 0; return; }
+    const Cand* frec = lvl_rec + (size_t)f * L * cap;
+    const int P = next_pow2(total);
+    for (int e = threadIdx.x; e < P; e += blockDim.x) {
+        if (e < total) {
+            int l = 0;
+            while (e >= offs[l + 1]) l++;
+            const int slot = keep_idx[((size_t)f * L + l) * cap + (e - offs[l])];
+            const uint32_t gid = (uint32_t)(l * cap + slot);
+            S.key[e] = (((uint64_t)(~f2ord(frec[gid].score))) << 32) | (uint32_t)e;   // e = position in the concatenated list
+            S.id[e] = gid;
+        } else {
+            S.key[e] = ~0ull; S.id[e] = 0;
+        }
+    }
+    __syncthreads();
+    block_bitonic(S.key, S.id, P);
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+        const Cand& c = frec[S.id[t]];
+        S.box[t] = make_float4(c.x1, c.y1, c.x2, c.y2);
+        S.area[t] = (c.x2 - c.x1) * (c.y2 - c.y1);
+    }
+    __syncthreads();
+    const int nk = block_nms<false>(S.box, S.area, total, 0.7f, S.sup, S.keep, S.scal);
+    // regress with the PNet offsets (w,h WITHOUT +1), rerec, drop empty clipped boxes
+    for (int r = threadIdx.x; r < nk; r += blockDim.x) {
+        const Cand& c = frec[S.id[S.keep[r]]];
+        const float regw = c.x2 - c.x1, regh = c.y2 - c.y1;
+        float x1 = c.x1 + c.r0 * regw, y1 = c.y1 + c.r1 * regh, x2 = c.x2 + c.r2 * regw, y2 = c.y2 + c.r3 * regh;
+        rerec1(x1, y1, x2, y2);
+        int y, ey, x, ex;
+        S.flg[r] = pad1(x1, y1, x2, y2, W, H, y, ey, x, ex) ? 1 : 0;
+        S.box[r] = make_float4(x1, y1, x2, y2);   // box[] no longer needed by NMS
+        S.aux[r] = c.score;
+    }
+    __syncthreads();
+    const int m = block_compact_positions(S.flg, nk, S.pos, S.part);
+    for (int r = threadIdx.x; r < nk; r += blockDim.x) {
+        if (!S.flg[r]) continue;
+        float* o = s1_box + ((size_t)f * capF + S.pos[r]) * 5;
+        const float4 b = S.box[r];
+        o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = S.aux[r];
+    }
+    if (threadIdx.x == 0) n1[f] = m;
+}
+
+// exclusive scan of per-frame counts; off[n] = total.  Also the candidate -> (frame, local) map.
+__global__ __launch_bounds__(256) void k_scan_counts(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off) {
+    extern __shared__ int sh[];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sh[i] = cnt[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < n; i++) { const int v = sh[i]; sh[i] = run; run += v; }
+        sh[n] = run;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) off[i] = sh[i];
+}
+__global__ void k_build_map(const int32_t* __restrict__ cnt, const int32_t* __restrict__ off, int32_t* __restrict__ map_frame,
+                            int32_t* __restrict__ map_local) {
+    const int f = blockIdx.x;
+    const int c = cnt[f], o = off[f];
+    for (int i = threadIdx.x; i < c; i += blockDim.x) { map_frame[o + i] = f; map_local[o + i] = i; }
+}
+
+// crop [y-1:ey, x-1:ex] + imresample to SxS + normalise, one workgroup per candidate
+__global__ __launch_bounds__(256) void k_crop_resample(const uint8_t* __restrict__ frames, int H, int W, int S_, int capF,
+                                                       const float* __restrict__ boxes, const int32_t* __restrict__ map_frame,
+                                                       const int32_t* __restrict__ map_local, int t0, float* __restrict__ out) {
+    const int t = t0 + blockIdx.x;
+    const int f = map_frame[t], i = map_local[t];
+    const float* b = boxes + ((size_t)f * capF + i) * 5;
+    int y, ey, x, ex;
+    pad1(b[0], b[1], b[2], b[3], W, H, y, ey, x, ex);
+    const int y0 = y - 1, x0 = x - 1, ih = ey - y0, iw = ex - x0;
+    const uint8_t* fp = frames + (size_t)f * H * W * 3;
+    float* o = out + (size_t)blockIdx.x * S_ * S_ * 3;
+    for (int p = threadIdx.x; p < S_ * S_; p += blockDim.x) {
+        const int oy = p / S_, ox = p - oy * S_;
+        const int ys = (oy * ih) / S_, ye = ((oy + 1) * ih + S_ - 1) / S_;
+        const int xs = (ox * iw) / S_, xe = ((ox + 1) * iw + S_ - 1) / S_;
+        unsigned s0 = 0, s1 = 0, s2 = 0;
+        for (int yy = ys; yy < ye; yy++) {
+            const uint8_t* q = fp + ((size_t)(y0 + yy) * W + x0 + xs) * 3;
+            for (int xx = xs; xx < xe; xx++, q += 3) { s0 += q[0]; s1 += q[1]; s2 += q[2]; }
+        }
+        const float kh = (float)(ye - ys), kw = (float)(xe - xs);
+        o[3 * p + 0] = ((float)s0 / kh / kw - 127.5f) * 0.0078125f;
+        o[3 * p + 1] = ((float)s1 / kh / kw - 127.5f) * 0.0078125f;
+        o[3 * p + 2] = ((float)s2 / kh / kw - 127.5f) * 0.0078125f;
+    }
+}
+
+// ---- stage 2 tail: thr1, batched_nms(0.7), bbreg, rerec ------------------------------------------
+__global__ __launch_bounds__(256) void k_stage2_post(int capF, int W, int H, float thr, const int32_t* __restrict__ n1,
+                                                     const float* __restrict__ s1_box, const int32_t* __restrict__ off2,
+                                                     const float* __restrict__ out6, int32_t* __restrict__ n2,
+                                                     float* __restrict__ s2_box) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem S(smem_raw, capF);
+    const int f = blockIdx.x;
+    const int cnt = n1[f];
+    if (cnt == 0) { if (threadIdx.x == 0) n2[f] = 0; return; }
+    const float* logits = out6 + (size_t)off2[f] * 6;
+    const float* fb = s1_box + (size_t)f * capF * 5;
+    const int P = next_pow2(cnt);
+    if (threadIdx.x == 0) S.scal[4] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        uint64_t k = ~0ull;
+        if (i < cnt) {
+            const float p = trl_softmax2_p1(logits[6 * i], logits[6 * i + 1]);
+            S.aux[i] = p;
+            if (p > thr) { k = (((uint64_t)(~f2ord(p))) << 32) | (uint32_t)i; atomicAdd(&S.scal[4], 1); }
+        }
+        S.key[i] = k; S.id[i] = i;
+    }
+    __syncthreads();
+    const int m = S.scal[4];
+    if (m == 0) { if (threadIdx.x == 0) n2[f] = 0; return; }
+    block_bitonic(S.key, S.id, P);
+    for (int t = threadIdx.x; t < m; t += blockDim.x) {
+        const float* b = fb + 5 * S.id[t];
+        S.box[t] = make_float4(b[0], b[1], b[2], b[3]);
+        S.area[t] = (b[2] - b[0]) * (b[3] - b[1]);
+    }
+    __syncthreads();
+    const int nk = block_nms<false>(S.box, S.area, m, 0.7f, S.sup, S.keep, S.scal);
+    // bbreg (+1 widths), rerec; rows go to s2_box provisionally at r, then are compacted in place
+    for (int r = threadIdx.x; r < nk; r += blockDim.x) {
+        const int i = (int)S.id[S.keep[r]];
+        const float4 b = S.box[S.keep[r]];
+        const float* g = logits + 6 * i + 2;
+        const float w = b.z - b.x + 1.f, h = b.w - b.y + 1.f;
+        float x1 = b.x + g[0] * w, y1 = b.y + g[1] * h, x2 = b.z + g[2] * w, y2 = b.w + g[3] * h;
+        rerec1(x1, y1, x2, y2);
+        int y, ey, x, ex;
+        S.flg[r] = pad1(x1, y1, x2, y2, W, H, y, ey, x, ex) ? 1 : 0;
+        float* o = s2_box + ((size_t)f * capF + r) * 5;
+        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = S.aux[i];
+    }
+    __syncthreads();
+    const int mm = block_compact_positions(S.flg, nk, S.pos, S.part);
+    // in-place ordered compaction (pos[r] <= r): rounds of blockDim rows, reads precede writes
+    float row[5];
+    for (int base = 0; base < nk; base += blockDim.x) {
+        const int r = base + threadIdx.x;
+        bool live = r < nk && S.flg[r];
+        if (live) { const float* o = s2_box + ((size_t)f * capF + r) * 5; for (int q = 0; q < 5; q++) row[q] = o[q]; }
+        __syncthreads();
+        if (live) { float* o = s2_box + ((size_t)f * capF + S.pos[r]) * 5; for (int q = 0; q < 5; q++) o[q] = row[q]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n2[f] = mm;
+}
+
+// ---- stage 3 tail: thr2, landmarks, bbreg, nms 'Min' 0.7 --------------------------------------
+__global__ __launch_bounds__(256) void k_stage3_post(int capF, float thr, const int32_t* __restrict__ n2, const float* __restrict__ s2_box,
+                                                     const int32_t* __restrict__ off3, const float* __restrict__ out16,
+                                                     int32_t* __restrict__ n3, float* __restrict__ s3_box, float* __restrict__ s3_pts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem S(smem_raw, capF);
+    const int f = blockIdx.x;
+    const int cnt = n2[f];
+    if (cnt == 0) { if (threadIdx.x == 0) n3[f] = 0; return; }
+    const float* logits = out16 + (size_t)off3[f] * 16;
+    const float* fb = s2_box + (size_t)f * capF * 5;
+    const int P = next_pow2(cnt);
+    if (threadIdx.x == 0) S.scal[4] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        uint64_t k = ~0ull;
+        if (i < cnt) {
+            const float p = trl_softmax2_p1(logits[16 * i], logits[16 * i + 1]);
+            S.aux[i] = p;
+            // np.argsort ascending then take-from-the-end: descending score, ties -> higher index first
+            if (p > thr) { k = (((uint64_t)(~f2ord(p))) << 32) | (uint32_t)(~(uint32_t)i); atomicAdd(&S.scal[4], 1); }
+        }
+        S.key[i] = k; S.id[i] = i;
+    }
+    __syncthreads();
+    const int m = S.scal[4];
+    if (m == 0) { if (threadIdx.x == 0) n3[f] = 0; return; }
+    block_bitonic(S.key, S.id, P);
+    for (int t = threadIdx.x; t < m; t += blockDim.x) {
+        const int i = (int)S.id[t];
+        const float* b = fb + 5 * i;
+        const float* g = logits + 16 * i + 2;
+        const float w = b[2] - b[0] + 1.f, h = b[3] - b[1] + 1.f;
+        const float x1 = b[0] + g[0] * w, y1 = b[1] + g[1] * h, x2 = b[2] + g[2] * w, y2 = b[3] + g[3] * h;   // bbreg
+        S.box[t] = make_float4(x1, y1, x2, y2);
+        S.area[t] = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
+    }
+    __syncthreads();
+    const int nk = block_nms<true>(S.box, S.area, m, 0.7f, S.sup, S.keep, S.scal);
+    for (int r = threadIdx.x; r < nk; r += blockDim.x) {
+        const int t = S.keep[r], i = (int)S.id[t];
+        const float4 bb = S.box[t];
+        float* o = s3_box + ((size_t)f * capF + r) * 5;
+        o[0] = bb.x; o[1] = bb.y; o[2] = bb.z; o[3] = bb.w; o[4] = S.aux[i];
+        const float* b = fb + 5 * i;
+        const float* pt = logits + 16 * i + 6;
+        const float w_i = b[2] - b[0] + 1.f, h_i = b[3] - b[1] + 1.f;
+        float* po = s3_pts + ((size_t)f * capF + r) * 10;
+        for (int j = 0; j < 5; j++) {
+            po[j] = w_i * pt[j] + b[0] - 1.f;
+            po[5 + j] = h_i * pt[5 + j] + b[1] - 1.f;
+        }
+    }
+    if (threadIdx.x == 0) n3[f] = nk;
+}
+
+// MTCNN.detect(select_largest=True) ordering + model.py:49-54
+__global__ __launch_bounds__(64) void k_select(int capF, int max_faces, int W, int H, const int32_t* __restrict__ n3,
+                                               const float* __restrict__ s3_box, float* __restrict__ boxes, float* __restrict__ probs,
+                                               int32_t* __restrict__ counts, float* __restrict__ box0, float* __restrict__ prob0,
+                                               int32_t* __restrict__ rect, uint8_t* __restrict__ valid) {
+    const int f = blockIdx.x;
+    const int n = n3[f];
+    const float* b = s3_box + (size_t)f * capF * 5;
+    // rank of r in np.argsort(area)[::-1] with stable-sort tie semantics: descending area, ties -> higher index first
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        const float ar = (b[5 * r + 2] - b[5 * r]) * (b[5 * r + 3] - b[5 * r + 1]);
+        int rank = 0;
+        for (int q = 0; q < n; q++) {
+            const float aq = (b[5 * q + 2] - b[5 * q]) * (b[5 * q + 3] - b[5 * q + 1]);
+            rank += (aq > ar) || (aq == ar && q > r);
+        }
+        if (boxes && rank < max_faces) {
+            float* o = boxes + ((size_t)f * max_faces + rank) * 4;
+            o[0] = b[5 * r]; o[1] = b[5 * r + 1]; o[2] = b[5 * r + 2]; o[3] = b[5 * r + 3];
+            probs[(size_t)f * max_faces + rank] = b[5 * r + 4];
+        }
+        if (rank == 0 && box0) {
+            box0[4 * f] = b[5 * r]; box0[4 * f + 1] = b[5 * r + 1]; box0[4 * f + 2] = b[5 * r + 2]; box0[4 * f + 3] = b[5 * r + 3];
+            prob0[f] = b[5 * r + 4];
+            // model.py:49-53: boxes[0].astype(int) (toward zero), clamp
+            long long x0 = (long long)b[5 * r], y0 = (long long)b[5 * r + 1], x1 = (long long)b[5 * r + 2], y1 = (long long)b[5 * r + 3];
+            if (x0 < 0) x0 = 0;
+            if (y0 < 0) y0 = 0;
+            if (x1 > W) x1 = W;
+            if (y1 > H) y1 = H;
+            rect[4 * f] = (int)x0; rect[4 * f + 1] = (int)y0; rect[4 * f + 2] = (int)x1; rect[4 * f + 3] = (int)y1;
+            valid[f] = (x1 > x0 && y1 > y0) ? 1 : 0;   // model.py:54
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (counts) counts[f] = n < max_faces ? n : max_faces;
+        if (n == 0 && box0) {
+            for (int q = 0; q < 4; q++) { box0[4 * f + q] = 0.f; rect[4 * f + q] = 0; }
+            prob0[f] = 0.f; valid[f] = 0;
+        }
+    }
+}
+
+// model.py:55-58: frame[y0:y1, x0:x1] -> cv2.resize(.., (80,80)) INTER_LINEAR (u8 fixed point) -> /255
+__device__ __forceinline__ int sat_short_round(float v) {
+    int r = (int)__builtin_rintf(v);
+    return r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+}
+__global__ __launch_bounds__(256) void k_crop_resize80(const uint8_t* __restrict__ frames, int H, int W, const int32_t* __restrict__ rect,
+                                                       const uint8_t* __restrict__ valid, float* __restrict__ out) {
+    constexpr int O = 80;
+    __shared__ int xofs[O], xofs1[O], a0[O], a1[O], ys0[O], ys1[O], b0[O], b1[O];
+    const int f = blockIdx.x;
+    float* o = out + (size_t)f * O * O * 3;
+    if (!valid[f]) {
+        for (int p = threadIdx.x; p < O * O * 3; p += blockDim.x) o[p] = 0.f;
+        return;
+    }
+    const int x0 = rect[4 * f], y0 = rect[4 * f + 1], sw = rect[4 * f + 2] - x0, sh = rect[4 * f + 3] - y0;
+    const double scale_x = 1. / ((double)O / sw), scale_y = 1. / ((double)O / sh);
+    if (threadIdx.x < O) {
+        const int d = threadIdx.x;
+        float fx = (float)((d + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[d] = sx; xofs1[d] = sx + 1 > sw - 1 ? sw - 1 : sx + 1;
+        a0[d] = sat_short_round((1.f - fx) * 2048.f); a1[d] = sat_short_round(fx * 2048.f);
+    } else if (threadIdx.x < 2 * O) {
+        const int d = threadIdx.x - O;
+        float fy = (float)((d + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        b0[d] = sat_short_round((1.f - fy) * 2048.f); b1[d] = sat_short_round(fy * 2048.f);
+        ys0[d] = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        ys1[d] = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+    }
+    __syncthreads();
+    const uint8_t* fp = frames + ((size_t)f * H + y0) * W * 3 + (size_t)x0 * 3;
+    for (int p = threadIdx.x; p < O * O * 3; p += blockDim.x) {
+        const int c = p % 3, dx = (p / 3) % O, dy = p / (3 * O);
+        const uint8_t* S0 = fp + (size_t)ys0[dy] * W * 3;
+        const uint8_t* S1 = fp + (size_t)ys1[dy] * W * 3;
+        const int r0 = S0[xofs[dx] * 3 + c] * a0[dx] + S0[xofs1[dx] * 3 + c] * a1[dx];
+        const int r1 = S1[xofs[dx] * 3 + c] * a0[dx] + S1[xofs1[dx] * 3 + c] * a1[dx];
+        int v = (((b0[dy] * (r0 >> 4)) >> 16) + ((b1[dy] * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        o[p] = (float)v / 255.0f;   // to_tensor
+    }
+}
+
+template <typename K>
+int set_dyn_smem(K kernel, size_t bytes) {
+    TRL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return TRL_OK;
+}
+
+int read_total(trl_ctx* c, const int32_t* d_off_n, int slot, hipStream_t s, int* out) {
+    TRL_HIP(hipMemcpyAsync(c->h_pinned + slot, d_off_n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    TRL_HIP(hipStreamSynchronize(s));
+    *out = c->h_pinned[slot];
+    return TRL_OK;
+}
+
+}  // namespace
+
+// ---- host helpers -------------------------------------------------------------------------------
+int trl_compute_levels(trl_ctx* c, int H, int W) {
+    // detect_face.py: m = 12/minsize; minl = min(h,w)*m; while minl >= 12: scales += [scale_i]; scale_i *= factor
+    const double m = 12.0 / c->cfg.min_face_size;
+    double minl = (H < W ? H : W) * m;
+    double scale_i = m;
+    int L = 0;
+    while (minl >= 12 && L < 32) {
+        LevelGeom& g = c->lv[L];
+        g.scale = scale_i;
+        g.h = (int)(H * scale_i + 1);
+        g.w = (int)(W * scale_i + 1);
+        const int ph = (g.h - 2 + 1) / 2, pw = (g.w - 2 + 1) / 2;
+        g.oh = ph - 4; g.ow = pw - 4;
+        L++;
+        scale_i = scale_i * c->cfg.factor;
+        minl = minl * c->cfg.factor;
+    }
+    return L;
+}
+
+int trl_launch_area_level(const uint8_t* d_frames, int nf, int H, int W, int h, int w, float* d_level, hipStream_t s) {
+    const size_t total = (size_t)nf * h * w;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    k_area_level<<<(unsigned)blocks, 256, 0, s>>>(d_frames, nf, H, W, h, w, d_level);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+int trl_launch_heads_to_maps(const float* d_heads, int cells, float* d_prob, float* d_reg, hipStream_t s) {
+    k_heads_to_maps<<<(cells + 255) / 256, 256, 0, s>>>(d_heads, cells, d_prob, d_reg);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+int trl_launch_crop_resize80(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid,
+                             float* d_faces, hipStream_t s) {
+    if (n <= 0) return TRL_OK;
+    k_crop_resize80<<<n, 256, 0, s>>>(d_frames, H, W, d_rect, d_valid, d_faces);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+
+
+
+// detect_face() stages 1-3 for n frames; results stay in c->cb
+int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipStream_t s) {
+    const int cap = c->cfg.cap_level, capF = c->cfg.cap_frame;
+    const int L = trl_compute_levels(c, H, W);
+    CascadeBufs& B = c->cb;
+    B.n = n; B.L = L; B.H = H; B.W = W;
+    Arena& A = c->arena;      // cascade lists: live for the whole call (and for the debug hooks after it)
+    Arena& X = c->scratch;    // activations: reset between stages
+    const size_t need = (size_t)n * L * ((size_t)cap * (sizeof(Cand) + 4) + 8) + (size_t)n * capF * (5 * 3 + 10 + 2) * 4 +
+                        (size_t)n * 128 + (1u << 20);
+    TRL_CHECK(trl_ensure(c, A, need));
+    A.reset();
+    B.lvl_cnt = (int32_t*)A.alloc((size_t)n * L * 4);
+    B.lvl_keep_cnt = (int32_t*)A.alloc((size_t)n * L * 4);
+    B.lvl_rec = (Cand*)A.alloc((size_t)n * L * cap * sizeof(Cand));
+    B.lvl_keep_idx = (int32_t*)A.alloc((size_t)n * L * cap * 4);
+    B.n1 = (int32_t*)A.alloc((size_t)n * 4); B.n2 = (int32_t*)A.alloc((size_t)n * 4); B.n3 = (int32_t*)A.alloc((size_t)n * 4);
+    B.s1_box = (float*)A.alloc((size_t)n * capF * 20); B.s2_box = (float*)A.alloc((size_t)n * capF * 20);
+    B.s3_box = (float*)A.alloc((size_t)n * capF * 20); B.s3_pts = (float*)A.alloc((size_t)n * capF * 40);
+    B.off2 = (int32_t*)A.alloc((size_t)(n + 1) * 4); B.off3 = (int32_t*)A.alloc((size_t)(n + 1) * 4);
+    B.map_frame = (int32_t*)A.alloc((size_t)n * capF * 4); B.map_local = (int32_t*)A.alloc((size_t)n * capF * 4);
+    B.flags = (int32_t*)A.alloc(64);
+    if (!B.flags) { trl_set_error("cascade workspace allocation failed"); return TRL_ERR_STATE; }
+    TRL_HIP(hipMemsetAsync(B.lvl_cnt, 0, (size_t)n * L * 4, s));
+    TRL_HIP(hipMemsetAsync(B.flags, 0, 64, s));
+
+    // ---- stage 1: PNet over the pyramid ----------------------------------------------------------
+    c->pnet_ev_used = 0;
+    X.reset();
+    int chunk[32];
+    if (c->cfg.pnet_mode != 0) {
+        size_t mx = 0;
+        for (int l = 0; l < L; l++) {
+            const LevelGeom& g = c->lv[l];
+            const size_t per = trl_pnet_generic_bytes(1, g.h, g.w) + (size_t)g.h * g.w * 12 + (size_t)g.oh * g.ow * 24 + 4096;
+            int ch = (int)((size_t)(2048ull << 20) / per);
+            if (ch < 1) ch = 1;
+            if (ch > n) ch = n;
+            chunk[l] = ch;
+            if (per * ch > mx) mx = per * ch;
+        }
+        TRL_CHECK(trl_ensure(c, X, mx + (4u << 20)));
+    }
+    for (int l = 0; l < L; l++) {
+        const LevelGeom& g = c->lv[l];
+        if (g.oh < 1 || g.ow < 1) continue;
+        if ((int)c->pnet_ev.size() <= c->pnet_ev_used) {
+            hipEvent_t e0, e1;
+            TRL_HIP(hipEventCreate(&e0)); TRL_HIP(hipEventCreate(&e1));
+            c->pnet_ev.push_back({e0, e1});
+        }
+        auto& ev = c->pnet_ev[c->pnet_ev_used++];
+        TRL_HIP(hipEventRecord(ev.first, s));
+        if (c->cfg.pnet_mode == 0) {
+            TRL_CHECK(trl_pnet_fused_level(c, d_frames, n, H, W, l, s));
+        } else {
+            // generic layer path: materialise the level for a chunk of frames
+            for (int f0 = 0; f0 < n; f0 += chunk[l]) {
+                const int nf = (n - f0 < chunk[l]) ? n - f0 : chunk[l];
+                X.reset();
+                float* lvl = (float*)X.alloc((size_t)nf * g.h * g.w * 12);
+                float* heads = (float*)X.alloc((size_t)nf * g.oh * g.ow * 24);
+                if (!lvl || !heads) { trl_set_error("pnet generic workspace"); return TRL_ERR_STATE; }
+                TRL_CHECK(trl_launch_area_level(d_frames + (size_t)f0 * H * W * 3, nf, H, W, g.h, g.w, lvl, s));
+                TRL_CHECK(trl_run_pnet_generic(c, lvl, nf, g.h, g.w, heads, s));
+                const size_t total = (size_t)nf * g.oh * g.ow;
+                size_t blocks = (total + 255) / 256;
+                if (blocks > 16384) blocks = 16384;
+                k_pnet_collect<<<(unsigned)blocks, 256, 0, s>>>(heads, nf, f0, g.oh, g.ow, (float)g.scale, c->cfg.thr0, L, l, cap,
+                                                                 B.lvl_cnt, B.lvl_rec, B.flags);
+                TRL_LAUNCH_CHECK();
+            }
+        }
+        TRL_HIP(hipEventRecord(ev.second, s));
+    }
+    const size_t sm_l = Smem::bytes(cap), sm_f = Smem::bytes(capF);
+    TRL_CHECK(set_dyn_smem(k_nms_level, sm_l));
+    TRL_CHECK(set_dyn_smem(k_nms_frame, sm_f));
+    TRL_CHECK(set_dyn_smem(k_stage2_post, sm_f));
+    TRL_CHECK(set_dyn_smem(k_stage3_post, sm_f));
+    k_nms_level<<<n * L, 256, sm_l, s>>>(L, cap, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags);
+    TRL_LAUNCH_CHECK();
+    k_nms_frame<<<n, 256, sm_f, s>>>(L, cap, capF, W, H, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.n1, B.s1_box, B.flags);
+    TRL_LAUNCH_CHECK();
+
+    // ---- stage 2: RNet ------------------------------------------------------------------------------
+    k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n1, n, B.off2);
+    TRL_LAUNCH_CHECK();
+    k_build_map<<<n, 64, 0, s>>>(B.n1, B.off2, B.map_frame, B.map_local);
+    TRL_LAUNCH_CHECK();
+    int T2 = 0;
+    TRL_CHECK(read_total(c, B.off2 + n, 0, s, &T2));   // host sync: everything before is complete, scratch is free
+    X.reset();
+    float* out6 = nullptr;
+    if (T2 > 0) {
+        const int CH = 16384;
+        const int chn = T2 < CH ? T2 : CH;
+        TRL_CHECK(trl_ensure(c, X, (size_t)T2 * 24 + (size_t)chn * (24 * 24 * 3 * 4 + 100 * 1024) + (1u << 20)));
+        out6 = (float*)X.alloc((size_t)T2 * 24);
+        const size_t mk = X.off;
+        for (int t0 = 0; t0 < T2; t0 += CH) {
+            const int nc = (T2 - t0 < CH) ? T2 - t0 : CH;
+            X.off = mk;
+            float* crops = (float*)X.alloc((size_t)nc * 24 * 24 * 3 * 4);
+            if (!crops || !out6) { trl_set_error("rnet workspace"); return TRL_ERR_STATE; }
+            k_crop_resample<<<nc, 256, 0, s>>>(d_frames, H, W, 24, capF, B.s1_box, B.map_frame, B.map_local, t0, crops);
+            TRL_LAUNCH_CHECK();
+            TRL_CHECK(trl_run_rnet(c, crops, nc, out6 + (size_t)t0 * 6, s));
+        }
+    }
+    k_stage2_post<<<n, 256, sm_f, s>>>(capF, W, H, c->cfg.thr1, B.n1, B.s1_box, B.off2, out6, B.n2, B.s2_box);
+    TRL_LAUNCH_CHECK();
+
+    // ---- stage 3: ONet --------------------------------------------------------------------------------
+    k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n2, n, B.off3);
+    TRL_LAUNCH_CHECK();
+    k_build_map<<<n, 64, 0, s>>>(B.n2, B.off3, B.map_frame, B.map_local);
+    TRL_LAUNCH_CHECK();
+    int T3 = 0;
+    TRL_CHECK(read_total(c, B.off3 + n, 1, s, &T3));   // host sync: stage 2 finished, scratch is free again
+    X.reset();
+    float* out16 = nullptr;
+    if (T3 > 0) {
+        const int CH = 4096;
+        const int chn = T3 < CH ? T3 : CH;
+        TRL_CHECK(trl_ensure(c, X, (size_t)T3 * 64 + (size_t)chn * (48 * 48 * 3 * 4 + 640 * 1024) + (1u << 20)));
+        out16 = (float*)X.alloc((size_t)T3 * 64);
+        const size_t mk = X.off;
+        for (int t0 = 0; t0 < T3; t0 += CH) {
+            const int nc = (T3 - t0 < CH) ? T3 - t0 : CH;
+            X.off = mk;
+            float* crops = (float*)X.alloc((size_t)nc * 48 * 48 * 3 * 4);
+            if (!crops || !out16) { trl_set_error("onet workspace"); return TRL_ERR_STATE; }
+            k_crop_resample<<<nc, 256, 0, s>>>(d_frames, H, W, 48, capF, B.s2_box, B.map_frame, B.map_local, t0, crops);
+            TRL_LAUNCH_CHECK();
+            TRL_CHECK(trl_run_onet(c, crops, nc, out16 + (size_t)t0 * 16, s));
+        }
+    }
+    k_stage3_post<<<n, 256, sm_f, s>>>(capF, c->cfg.thr2, B.n2, B.s2_box, B.off3, out16, B.n3, B.s3_box, B.s3_pts);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+
+int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, int32_t* d_counts,
+                       float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, hipStream_t s) {
+    (void)d_frames;
+    CascadeBufs& B = c->cb;
+    k_select<<<n, 64, 0, s>>>(c->cfg.cap_frame, c->cfg.max_faces, W, H, B.n3, B.s3_box, d_boxes, d_probs, d_counts, d_box0, d_prob0,
+                              d_rect, d_valid);
+    TRL_LAUNCH_CHECK();
+    // capacity overflow is an error, not a silent truncation
+    TRL_HIP(hipMemcpyAsync(c->h_pinned + 4, B.flags, 16, hipMemcpyDeviceToHost, s));
+    TRL_HIP(hipStreamSynchronize(s));
+    if (c->h_pinned[4] || c->h_pinned[5]) {
+        trl_set_error("candidate list overflow (cap_level=%d%s, cap_frame=%d%s): raise the capacities in trl_config",
+                      c->cfg.cap_level, c->h_pinned[4] ? " EXCEEDED" : "", c->cfg.cap_frame, c->h_pinned[5] ? " EXCEEDED" : "");
+        return TRL_ERR_CAPACITY;
+    }
+    return TRL_OK;
+}

@@ -1,0 +1,130 @@
+// trl_common.h -- shared declarations of libtruely_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/truely_hip.h"
+
+// ---- error plumbing --------------------------------------------------------------------------
+void trl_set_error(const char* fmt, ...);
+#define TRL_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            trl_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return TRL_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+#define TRL_CHECK(expr)                       \
+    do {                                      \
+        int s__ = (expr);                     \
+        if (s__ != TRL_OK) return s__;        \
+    } while (0)
+#define TRL_LAUNCH_CHECK() TRL_HIP(hipGetLastError())
+
+// ---- device tensors ---------------------------------------------------------------------------
+struct DevW {          // a weight matrix on the device, [Kpad][ld] row-major, zero padded
+    float* p = nullptr;
+    int K = 0, Cout = 0, Kpad = 0, ld = 0;
+};
+struct DevV {          // a per-channel vector, padded to a multiple of 128 floats
+    float* p = nullptr;
+    int n = 0;
+};
+
+// NHWC activation view
+struct Act {
+    float* p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0;   // c = channels of this view
+    int ld = 0;                        // floats between consecutive pixels (>= c)
+    int coff = 0;                      // channel offset of the view inside the pixel
+    size_t pixels() const { return (size_t)n * h * w; }
+};
+
+enum { TRL_ACT_NONE = 0, TRL_ACT_RELU = 1, TRL_ACT_PRELU = 2 };
+
+struct ConvArgs {
+    const float* x; int N, H, W, Cin, ldx, xoff;
+    const float* w; int ldw, K;
+    const float* bias;            // accumulator init (or null -> 0)
+    const float* scale; const float* shift;   // folded BN (or null)
+    const float* slope;           // PReLU (act == PRELU)
+    const float* res; int ldres; float res_scale;   // residual: v = v*res_scale + res
+    float* y; int ldy, yoff;
+    int KH, KW, sh, sw, ph, pw, Cout, OH, OW, act;
+    int M;                        // N*OH*OW
+};
+
+// bump allocator over one device allocation
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    void reset() { off = 0; }
+    void* alloc(size_t bytes) {
+        size_t a = (off + 255) & ~(size_t)255;
+        if (a + bytes > cap) return nullptr;
+        off = a + bytes;
+        return base + a;
+    }
+};
+
+// ---- kernels (launch wrappers) ----------------------------------------------------------------
+int trl_launch_conv(const ConvArgs& a, hipStream_t s);
+int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st,
+                       int ceil_mode, float* y, int ldy, int yoff, int OH, int OW, hipStream_t s);
+int trl_launch_gap(const float* x, int N, int HW, int C, float* y, hipStream_t s);
+int trl_launch_l2norm512(const float* x, const uint8_t* valid, int n, float* y, hipStream_t s);
+int trl_launch_drift(const float* emb, const uint8_t* valid, int n, long long frame_count, int fps,
+                     float* sims, uint8_t* flags, int32_t* result, hipStream_t s);
+
+static inline int trl_pool_out(int L, int k, int s, int ceil_mode) {
+    int o;
+    if (ceil_mode) {
+        o = (L - k + s - 1) / s + 1;
+        if ((o - 1) * s >= L) o--;
+    } else {
+        o = (L - k) / s + 1;
+    }
+    return o;
+}
+
+// ---- device math shared with the oracle (oracle/trl_oracle.c: orc_expf, softmax2_p1, orc_dot512)
+#ifdef __HIPCC__
+// Same operation sequence as orc_expf; with -ffp-contract=off every op rounds once, as on the CPU.
+__device__ __forceinline__ float trl_expf(float x) {
+    if (x < -87.0f) x = -87.0f;
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    int e = (int)n;
+    float s = __uint_as_float((unsigned)(e + 127) << 23);
+    return y * s;
+}
+__device__ __forceinline__ float trl_softmax2_p1(float a0, float a1) {
+    float m = a0 > a1 ? a0 : a1;
+    float e0 = trl_expf(a0 - m), e1 = trl_expf(a1 - m);
+    return e1 / (e0 + e1);
+}
+// 512-long dot by ONE wave: lane j accumulates elements j+64*i (i ascending, fmaf), then an xor
+// butterfly (32,16,...,1).  Every lane returns the same value.  Mirrors orc_dot512.
+__device__ __forceinline__ float trl_wave_dot512(const float* a, const float* b, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s = __builtin_fmaf(a[lane + 64 * i], b[lane + 64 * i], s);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+    return s;
+}
+#endif

@@ -1,0 +1,74 @@
+// trl_ctx.h -- the opaque context behind the C ABI.
+#pragma once
+#include "trl_common.h"
+
+// One PNet candidate (generateBoundingBox row + its cell index).  40 bytes.
+struct Cand {
+    float x1, y1, x2, y2, score;
+    float r0, r1, r2, r3;
+    int cell;
+};
+
+struct LevelGeom {
+    double scale;
+    int h, w;        // pyramid level size
+    int oh, ow;      // PNet output map size
+};
+
+struct CascadeBufs {   // device pointers into the arena, valid until the next call
+    int n = 0, L = 0, H = 0, W = 0;
+    int32_t* lvl_cnt = nullptr;      // [n][L]
+    Cand* lvl_rec = nullptr;         // [n][L][cap_level]
+    int32_t* lvl_keep_cnt = nullptr; // [n][L]
+    int32_t* lvl_keep_idx = nullptr; // [n][L][cap_level]
+    int32_t* n1 = nullptr; float* s1_box = nullptr;   // [n], [n][cap_frame][5]
+    int32_t* n2 = nullptr; float* s2_box = nullptr;   // [n], [n][cap_frame][5]
+    int32_t* n3 = nullptr; float* s3_box = nullptr;   // [n], [n][cap_frame][5]
+    float* s3_pts = nullptr;                           // [n][cap_frame][10]
+    int32_t* off2 = nullptr; int32_t* off3 = nullptr; // [n+1] exclusive scans of n1 / n2
+    int32_t* map_frame = nullptr; int32_t* map_local = nullptr;  // [n*cap_frame]
+    int32_t* flags = nullptr;        // [4]: overflow flags
+};
+
+struct trl_ctx {
+    trl_config cfg;
+    bool have_weights = false;
+    char* wdev = nullptr;            // all weights, device
+    size_t wbytes = 0;
+    std::unordered_map<std::string, DevW> W;
+    std::unordered_map<std::string, DevV> V;
+    Arena arena;                     // per-call persistent blocks (cascade lists)
+    Arena scratch;                   // transient activations; only ever grown while empty
+    int32_t* h_pinned = nullptr;     // small pinned host scratch
+    CascadeBufs cb;
+    LevelGeom lv[32];
+    hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pnet_ev;
+    int pnet_ev_used = 0;
+    float last_ms[3] = {0, 0, 0};
+};
+
+int trl_ensure(trl_ctx* c, Arena& a, size_t bytes);   // grow (never while blocks of `a` are live)
+const DevW* trl_w(trl_ctx* c, const std::string& name);
+const DevV* trl_v(trl_ctx* c, const std::string& name);
+
+// networks (trl_nets.hip)
+int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const uint8_t* d_valid, float* d_emb, hipStream_t s);
+int trl_run_rnet(trl_ctx* c, const float* d_crops, int n, float* d_out6, hipStream_t s);
+int trl_run_onet(trl_ctx* c, const float* d_crops, int n, float* d_out16, hipStream_t s);
+// PNet on one materialised level for nf frames: heads [nf][oh][ow][6]
+int trl_run_pnet_generic(trl_ctx* c, const float* d_level, int nf, int h, int w, float* d_heads, hipStream_t s);
+size_t trl_pnet_generic_bytes(int nf, int h, int w);
+
+// cascade (trl_cascade.hip)
+int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipStream_t s);
+int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs,
+                       int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, hipStream_t s);
+int trl_launch_crop_resize80(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid,
+                             float* d_faces, hipStream_t s);
+int trl_launch_area_level(const uint8_t* d_frames, int nf, int H, int W, int h, int w, float* d_level, hipStream_t s);
+int trl_launch_heads_to_maps(const float* d_heads, int cells, float* d_prob, float* d_reg, hipStream_t s);
+int trl_compute_levels(trl_ctx* c, int H, int W);
+// fused PNet (trl_pnet.hip)
+int trl_pnet_prepare(trl_ctx* c);
+int trl_pnet_fused_level(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, int l, hipStream_t s);

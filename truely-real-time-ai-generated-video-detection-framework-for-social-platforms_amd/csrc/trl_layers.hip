@@ -1,0 +1,336 @@
+// trl_layers.hip -- generic NHWC layer kernels for gfx950 (MI355X).
+//
+// conv_igemm: implicit-GEMM convolution on the f32 matrix cores.
+//   GEMM view   M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin, k = (ky*KW+kx)*Cin + c.
+//   MFMA        v_mfma_f32_32x32x2_f32: one instruction = two chained fmaf per accumulator
+//               (k, k+1), bit-identical to the scalar chain acc = fmaf(x[k], w[k], acc) with k
+//               ascending (MI355X_MICROARCH "FP32-input MFMA").  The K loop below walks k in
+//               ascending order and the accumulator starts at the bias, so the result equals
+//               the oracle's conv2d() bit for bit whatever the tile shape.
+//   layout      output channel on the MFMA column (= lane), pixels on the rows: per-channel
+//               epilogue constants are lane constants and a store instruction writes 128-byte
+//               channel runs of NHWC.
+//   staging     A (pixels x k) gathered from NHWC into LDS as [k][m]; B (k x cout) as [k][n];
+//               ds_read_b32 operand reads are conflict-free (32 consecutive floats per half-wave).
+//               Next chunk's global loads are issued before the MFMAs of the current chunk.
+#include "trl_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 16;
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int ASLOTS = BM * 4, APT = (ASLOTS + 255) / 256;
+    constexpr int BSLOTS = BN * 4, BPT = (BSLOTS + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float As[BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- per-thread A row ------------------------------------------------------------------
+    const int row = tid % BM;
+    const int m = m0 + row;
+    const bool mvalid = m < a.M;
+    const int mm = mvalid ? m : 0;
+    const int ohw = a.OH * a.OW;
+    const int nimg = mm / ohw;
+    const int rem = mm - nimg * ohw;
+    const int oy = rem / a.OW, ox = rem - oy * a.OW;
+    const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
+    const float* xbase = a.x + (size_t)nimg * a.H * a.W * a.ldx + a.xoff;
+
+    float4 areg[APT];
+    float4 breg[BPT];
+
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < APT; i++) {
+            const int slot = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot < ASLOTS && mvalid) {
+                const int k = k0 + 4 * (slot / BM);
+                if (VEC) {
+                    if (k < a.K) {
+                        const int tap = k / a.Cin, c = k - tap * a.Cin;
+                        const int ky = tap / a.KW, kx = tap - ky * a.KW;
+                        const int iy = iy0 + ky, ix = ix0 + kx;
+                        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                            v = *reinterpret_cast<const float4*>(xbase + ((size_t)iy * a.W + ix) * a.ldx + c);
+                    }
+                } else {
+                    float t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int kk = k + j;
+                        t[j] = 0.f;
+                        if (kk < a.K) {
+                            const int tap = kk / a.Cin, c = kk - tap * a.Cin;
+                            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+                            const int iy = iy0 + ky, ix = ix0 + kx;
+                            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                                t[j] = xbase[((size_t)iy * a.W + ix) * a.ldx + c];
+                        }
+                    }
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            const int slot = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot < BSLOTS) {
+                const int kk = slot / (BN / 4), n = n0 + 4 * (slot % (BN / 4));
+                if (n < a.ldw) v = *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + kk) * a.ldw + n);
+            }
+            breg[i] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < APT; i++) {
+            const int slot = tid + i * 256;
+            if (slot < ASLOTS) {
+                const int g = slot / BM;
+                As[(4 * g + 0) * BM + row] = areg[i].x;
+                As[(4 * g + 1) * BM + row] = areg[i].y;
+                As[(4 * g + 2) * BM + row] = areg[i].z;
+                As[(4 * g + 3) * BM + row] = areg[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            const int slot = tid + i * 256;
+            if (slot < BSLOTS) {
+                const int kk = slot / (BN / 4), n4 = slot % (BN / 4);
+                *reinterpret_cast<float4*>(&Bs[kk * BN + 4 * n4]) = breg[i];
+            }
+        }
+    };
+
+    // ---- accumulators start at the bias (chain head) ---------------------------------------
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        const int n = n0 + (wn * TN + tn) * 32 + r;
+        const float b = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[tm][tn][i] = b;
+    }
+
+    const int nchunks = (a.K + BK - 1) / BK;
+    load_chunk(0);
+    for (int ch = 0; ch < nchunks; ch++) {
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
+#pragma unroll
+        for (int s = 0; s < BK / 2; s++) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) av[tm] = As[(2 * s + h) * BM + (wm * TM + tm) * 32 + r];
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) bv[tn] = Bs[(2 * s + h) * BN + (wn * TN + tn) * 32 + r];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        const int n = n0 + (wn * TN + tn) * 32 + r;
+        if (n >= a.Cout) continue;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        const float sf = a.scale ? a.shift[n] : 0.f;
+        const float sl = a.act == TRL_ACT_PRELU ? a.slope[n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int mr = m0 + (wm * TM + tm) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (mr >= a.M) continue;
+                float v = acc[tm][tn][i];
+                if (a.scale) v = __builtin_fmaf(v, sc, sf);
+                if (a.res) {
+                    v = v * a.res_scale;
+                    v = v + a.res[(size_t)mr * a.ldres + n];
+                }
+                if (a.act == TRL_ACT_RELU) v = v > 0.f ? v : 0.f;
+                else if (a.act == TRL_ACT_PRELU) v = v > 0.f ? v : sl * v;
+                a.y[(size_t)mr * a.ldy + a.yoff + n] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const ConvArgs& a, bool vec, hipStream_t s) {
+    dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    if (vec) conv_igemm<BM, BN, WM, WN, true><<<grid, 256, 0, s>>>(a);
+    else conv_igemm<BM, BN, WM, WN, false><<<grid, 256, 0, s>>>(a);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+
+// ---- max pool -------------------------------------------------------------------------------
+__global__ void maxpool_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx, int xoff,
+                               int k, int st, float* __restrict__ y, int ldy, int yoff, int OH, int OW) {
+    const size_t total = (size_t)N * OH * OW * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        size_t pix = idx / C;
+        const int ox = (int)(pix % OW); pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        float best = -INFINITY;
+        for (int ky = 0; ky < k; ky++) {
+            const int iy = oy * st + ky;
+            if (iy >= H) break;
+            for (int kx = 0; kx < k; kx++) {
+                const int ix = ox * st + kx;
+                if (ix >= W) break;
+                const float v = x[(((size_t)n * H + iy) * W + ix) * ldx + xoff + c];
+                best = v > best ? v : best;
+            }
+        }
+        y[(((size_t)n * OH + oy) * OW + ox) * ldy + yoff + c] = best;
+    }
+}
+
+// AdaptiveAvgPool2d(1): sequential row-major sum / count (oracle order)
+__global__ void gap_kernel(const float* __restrict__ x, int N, int HW, int C, float* __restrict__ y) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * C) return;
+    const int n = idx / C, c = idx - n * C;
+    float s = 0.f;
+    for (int p = 0; p < HW; p++) s = s + x[((size_t)n * HW + p) * C + c];
+    y[idx] = s / (float)HW;
+}
+
+// F.normalize(p=2, dim=1, eps=1e-12) on [n][512]; one wave per row.
+__global__ __launch_bounds__(64) void l2norm512_kernel(const float* __restrict__ x, const uint8_t* __restrict__ valid,
+                                                       int n, float* __restrict__ y) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    if (row >= n) return;
+    const float* v = x + (size_t)row * 512;
+    float* o = y + (size_t)row * 512;
+    if (valid && !valid[row]) {
+        for (int i = 0; i < 8; i++) o[lane + 64 * i] = 0.f;
+        return;
+    }
+    float nrm = sqrtf(trl_wave_dot512(v, v, lane));
+    if (nrm < 1e-12f) nrm = 1e-12f;
+    for (int i = 0; i < 8; i++) o[lane + 64 * i] = v[lane + 64 * i] / nrm;
+}
+
+// server/model.py:60-66,70,75,86-95 -- one wave walks the sampled frames in time order.
+__global__ __launch_bounds__(64) void drift_kernel(const float* __restrict__ emb, const uint8_t* __restrict__ valid, int n,
+                                                   long long frame_count, int fps, float* __restrict__ sims,
+                                                   uint8_t* __restrict__ flags, int32_t* __restrict__ result) {
+    const int lane = threadIdx.x;
+    const float thr_sim = 0.99f;   // model.py:16
+    const int thr_frames = 15;     // model.py:17
+    int run = 0, hits = 0, prev = -1;
+    float nprev = 0.f;
+    for (int i = 0; i < n; i++) {
+        float sim = 2.0f;
+        uint8_t flag = 0;
+        if (valid[i]) {   // wave-uniform
+            const float* cur = emb + (size_t)i * 512;
+            const float ncur = sqrtf(trl_wave_dot512(cur, cur, lane));
+            if (prev >= 0) {
+                const float d = trl_wave_dot512(cur, emb + (size_t)prev * 512, lane);
+                sim = d / (ncur * nprev);
+                run = (sim < thr_sim) ? run + 1 : 0;
+                if (run > thr_frames) { hits++; flag = 1; }
+            }
+            prev = i;
+            nprev = ncur;
+        }
+        if (lane == 0) {
+            if (sims) sims[i] = sim;
+            if (flags) flags[i] = flag;
+        }
+    }
+    if (lane == 0) {
+        int score = 0;
+        long long total = 0;
+        if (frame_count > 0 && fps > 0) {
+            int step = (int)((double)fps / 7.0);
+            if (step < 1) step = 1;
+            total = (frame_count + step - 1) / step;
+            if (total > 0) {
+                double pct = ((double)hits / (double)total) * 100.0;
+                double conf = pct * ((double)run / (double)thr_frames);
+                if (conf > 100.0) conf = 100.0;
+                const double w = (frame_count > (long long)fps * 30) ? 0.5 : 0.3;
+                double ws = pct + conf * w;
+                if (ws > 100.0) ws = 100.0;
+                score = (int)ws;
+                if (score < 0) score = 0;
+                if (score > 100) score = 100;
+            }
+        }
+        result[0] = score; result[1] = run; result[2] = hits; result[3] = (int32_t)total;
+    }
+}
+
+}  // namespace
+
+int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
+    if (a.M <= 0) return TRL_OK;
+    const bool vec = (a.Cin % 4 == 0) && (a.ldx % 4 == 0) && (a.xoff % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
+    if (a.Cout <= 32) return launch_cfg<128, 32, 4, 1>(a, vec, s);
+    if (a.M >= 16384) return launch_cfg<128, 64, 2, 2>(a, vec, s);
+    if (a.M >= 1024) return launch_cfg<64, 64, 2, 2>(a, vec, s);
+    return launch_cfg<32, 128, 1, 4>(a, vec, s);
+}
+
+int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st, int ceil_mode,
+                       float* y, int ldy, int yoff, int OH, int OW, hipStream_t s) {
+    (void)ceil_mode;
+    const size_t total = (size_t)N * OH * OW * C;
+    if (total == 0) return TRL_OK;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    maxpool_kernel<<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+
+int trl_launch_gap(const float* x, int N, int HW, int C, float* y, hipStream_t s) {
+    if (N * C == 0) return TRL_OK;
+    gap_kernel<<<(N * C + 255) / 256, 256, 0, s>>>(x, N, HW, C, y);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+
+int trl_launch_l2norm512(const float* x, const uint8_t* valid, int n, float* y, hipStream_t s) {
+    if (n <= 0) return TRL_OK;
+    l2norm512_kernel<<<n, 64, 0, s>>>(x, valid, n, y);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+
+int trl_launch_drift(const float* emb, const uint8_t* valid, int n, long long frame_count, int fps, float* sims,
+                     uint8_t* flags, int32_t* result, hipStream_t s) {
+    drift_kernel<<<1, 64, 0, s>>>(emb, valid, n, frame_count, fps, sims, flags, result);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}

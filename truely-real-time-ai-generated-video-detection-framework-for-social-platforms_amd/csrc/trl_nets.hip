@@ -1,0 +1,228 @@
+// trl_nets.hip -- host-side walkers that issue the layer kernels of the four networks.
+//
+// Architecture restated from the published facenet_pytorch 2.6.0 modules (absent from
+// /root/reference), call sites server/model.py:18-19,47,59.
+// Activations are NHWC f32 in the context arena; a concat is a channel slice of a wider
+// buffer (Act.coff / Act.ld), so torch.cat costs nothing.
+#include "trl_ctx.h"
+
+namespace {
+
+struct Runner {
+    trl_ctx* c;
+    hipStream_t s;
+    int err = TRL_OK;
+
+    Act alloc(int n, int h, int w, int ch) {
+        Act a;
+        a.n = n; a.h = h; a.w = w; a.c = ch; a.ld = ch; a.coff = 0;
+        a.p = (float*)c->scratch.alloc((size_t)n * h * w * ch * sizeof(float) + 64);
+        if (!a.p && err == TRL_OK) {
+            trl_set_error("activation scratch exhausted (%zu of %zu bytes used)", c->scratch.off, c->scratch.cap);
+            err = TRL_ERR_STATE;
+        }
+        return a;
+    }
+    static Act slice(const Act& buf, int coff, int ch) {
+        Act a = buf;
+        a.coff = buf.coff + coff;
+        a.c = ch;
+        return a;
+    }
+
+    // generic conv launcher; `into` selects a pre-allocated (concat) destination view
+    Act conv(const Act& x, const DevW* w, const DevV* bias, const DevV* scale, const DevV* shift, const DevV* slope,
+             int kh, int kw, int sh, int sw, int ph, int pw, int act, const Act* into, const Act* res, float res_scale) {
+        const int OH = (x.h + 2 * ph - kh) / sh + 1, OW = (x.w + 2 * pw - kw) / sw + 1;
+        Act y = into ? *into : alloc(x.n, OH, OW, w ? w->Cout : 0);
+        if (err != TRL_OK) return y;
+        if (!w || w->K != kh * kw * x.c || (into && (into->h != OH || into->w != OW || into->c != w->Cout))) {
+            trl_set_error("conv shape mismatch (K=%d expected %d)", w ? w->K : -1, kh * kw * x.c);
+            err = TRL_ERR_WEIGHTS;
+            return y;
+        }
+        ConvArgs a;
+        a.x = x.p; a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.ldx = x.ld; a.xoff = x.coff;
+        a.w = w->p; a.ldw = w->ld; a.K = w->K;
+        a.bias = bias ? bias->p : nullptr;
+        a.scale = scale ? scale->p : nullptr; a.shift = shift ? shift->p : nullptr;
+        a.slope = slope ? slope->p : nullptr;
+        a.res = res ? res->p + res->coff : nullptr; a.ldres = res ? res->ld : 0; a.res_scale = res_scale;
+        a.y = y.p; a.ldy = y.ld; a.yoff = y.coff;
+        a.KH = kh; a.KW = kw; a.sh = sh; a.sw = sw; a.ph = ph; a.pw = pw;
+        a.Cout = w->Cout; a.OH = OH; a.OW = OW; a.act = act;
+        a.M = x.n * OH * OW;
+        int st = trl_launch_conv(a, s);
+        if (st != TRL_OK) err = st;
+        return y;
+    }
+    // BasicConv2d: conv(no bias) + folded BN + ReLU
+    Act bconv(const Act& x, const std::string& name, int kh, int kw, int sh, int sw, int ph, int pw, const Act* into = nullptr) {
+        return conv(x, trl_w(c, name + ".w"), nullptr, trl_v(c, name + ".scale"), trl_v(c, name + ".shift"), nullptr,
+                    kh, kw, sh, sw, ph, pw, TRL_ACT_RELU, into, nullptr, 0.f);
+    }
+    // MTCNN conv (bias) + optional PReLU, valid padding
+    Act mconv(const Act& x, const std::string& net, const std::string& name, const char* prelu, int k) {
+        return conv(x, trl_w(c, net + "." + name + ".w"), trl_v(c, net + "." + name + ".b"), nullptr, nullptr,
+                    prelu ? trl_v(c, net + "." + prelu) : nullptr, k, k, 1, 1, 0, 0, prelu ? TRL_ACT_PRELU : TRL_ACT_NONE,
+                    nullptr, nullptr, 0.f);
+    }
+    Act resid(const Act& cat, const Act& x, const std::string& name, float scale, bool relu) {
+        return conv(cat, trl_w(c, name + ".w"), trl_v(c, name + ".b"), nullptr, nullptr, nullptr, 1, 1, 1, 1, 0, 0,
+                    relu ? TRL_ACT_RELU : TRL_ACT_NONE, nullptr, &x, scale);
+    }
+    Act pool(const Act& x, int k, int st, int ceil_mode, const Act* into = nullptr) {
+        const int OH = trl_pool_out(x.h, k, st, ceil_mode), OW = trl_pool_out(x.w, k, st, ceil_mode);
+        Act y = into ? *into : alloc(x.n, OH, OW, x.c);
+        if (err != TRL_OK) return y;
+        int e = trl_launch_maxpool(x.p, x.n, x.h, x.w, x.c, x.ld, x.coff, k, st, ceil_mode, y.p, y.ld, y.coff, OH, OW, s);
+        if (e != TRL_OK) err = e;
+        return y;
+    }
+};
+
+Act block35(Runner& R, const Act& x, const std::string& p) {
+    Act cat = R.alloc(x.n, x.h, x.w, 96);
+    Act s0 = Runner::slice(cat, 0, 32), s1 = Runner::slice(cat, 32, 32), s2 = Runner::slice(cat, 64, 32);
+    R.bconv(x, p + ".branch0", 1, 1, 1, 1, 0, 0, &s0);
+    Act a = R.bconv(x, p + ".branch1.0", 1, 1, 1, 1, 0, 0);
+    R.bconv(a, p + ".branch1.1", 3, 3, 1, 1, 1, 1, &s1);
+    Act b = R.bconv(x, p + ".branch2.0", 1, 1, 1, 1, 0, 0);
+    Act b2 = R.bconv(b, p + ".branch2.1", 3, 3, 1, 1, 1, 1);
+    R.bconv(b2, p + ".branch2.2", 3, 3, 1, 1, 1, 1, &s2);
+    return R.resid(cat, x, p + ".conv2d", 0.17f, true);
+}
+Act block17(Runner& R, const Act& x, const std::string& p) {
+    Act cat = R.alloc(x.n, x.h, x.w, 256);
+    Act s0 = Runner::slice(cat, 0, 128), s1 = Runner::slice(cat, 128, 128);
+    R.bconv(x, p + ".branch0", 1, 1, 1, 1, 0, 0, &s0);
+    Act a = R.bconv(x, p + ".branch1.0", 1, 1, 1, 1, 0, 0);
+    Act a2 = R.bconv(a, p + ".branch1.1", 1, 7, 1, 1, 0, 3);
+    R.bconv(a2, p + ".branch1.2", 7, 1, 1, 1, 3, 0, &s1);
+    return R.resid(cat, x, p + ".conv2d", 0.10f, true);
+}
+Act block8(Runner& R, const Act& x, const std::string& p, float scale, bool relu) {
+    Act cat = R.alloc(x.n, x.h, x.w, 384);
+    Act s0 = Runner::slice(cat, 0, 192), s1 = Runner::slice(cat, 192, 192);
+    R.bconv(x, p + ".branch0", 1, 1, 1, 1, 0, 0, &s0);
+    Act a = R.bconv(x, p + ".branch1.0", 1, 1, 1, 1, 0, 0);
+    Act a2 = R.bconv(a, p + ".branch1.1", 1, 3, 1, 1, 0, 1);
+    R.bconv(a2, p + ".branch1.2", 3, 1, 1, 1, 1, 0, &s1);
+    return R.resid(cat, x, p + ".conv2d", scale, relu);
+}
+
+}  // namespace
+
+// InceptionResnetV1.eval().forward (server/model.py:59)
+int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const uint8_t* d_valid, float* d_emb, hipStream_t s) {
+    if (n <= 0) return TRL_OK;
+    Runner R{c, s};
+    Act x0; x0.p = const_cast<float*>(d_faces); x0.n = n; x0.h = h; x0.w = w; x0.c = 3; x0.ld = 3; x0.coff = 0;
+    const std::string f = "facenet.";
+    Act x = R.bconv(x0, f + "conv2d_1a", 3, 3, 2, 2, 0, 0);
+    x = R.bconv(x, f + "conv2d_2a", 3, 3, 1, 1, 0, 0);
+    x = R.bconv(x, f + "conv2d_2b", 3, 3, 1, 1, 1, 1);
+    x = R.pool(x, 3, 2, 0);
+    x = R.bconv(x, f + "conv2d_3b", 1, 1, 1, 1, 0, 0);
+    x = R.bconv(x, f + "conv2d_4a", 3, 3, 1, 1, 0, 0);
+    x = R.bconv(x, f + "conv2d_4b", 3, 3, 2, 2, 0, 0);
+    if (R.err != TRL_OK) return R.err;
+    if (x.h < 3 || x.w < 3) { trl_set_error("face crop %dx%d too small for InceptionResnetV1", h, w); return TRL_ERR_INVALID; }
+    for (int i = 0; i < 5; i++) x = block35(R, x, f + "repeat_1." + std::to_string(i));
+    {   // Mixed_6a
+        const int OH = (x.h - 3) / 2 + 1, OW = (x.w - 3) / 2 + 1;
+        Act cat = R.alloc(n, OH, OW, 896);
+        Act s0 = Runner::slice(cat, 0, 384), s1 = Runner::slice(cat, 384, 256), s2 = Runner::slice(cat, 640, 256);
+        R.bconv(x, f + "mixed_6a.branch0", 3, 3, 2, 2, 0, 0, &s0);
+        Act a = R.bconv(x, f + "mixed_6a.branch1.0", 1, 1, 1, 1, 0, 0);
+        Act a2 = R.bconv(a, f + "mixed_6a.branch1.1", 3, 3, 1, 1, 1, 1);
+        R.bconv(a2, f + "mixed_6a.branch1.2", 3, 3, 2, 2, 0, 0, &s1);
+        R.pool(x, 3, 2, 0, &s2);
+        x = cat;
+    }
+    if (R.err != TRL_OK) return R.err;
+    if (x.h < 3 || x.w < 3) { trl_set_error("face crop %dx%d too small for InceptionResnetV1", h, w); return TRL_ERR_INVALID; }
+    for (int i = 0; i < 10; i++) x = block17(R, x, f + "repeat_2." + std::to_string(i));
+    {   // Mixed_7a
+        const int OH = (x.h - 3) / 2 + 1, OW = (x.w - 3) / 2 + 1;
+        Act cat = R.alloc(n, OH, OW, 1792);
+        Act s0 = Runner::slice(cat, 0, 384), s1 = Runner::slice(cat, 384, 256), s2 = Runner::slice(cat, 640, 256),
+            s3 = Runner::slice(cat, 896, 896);
+        Act a = R.bconv(x, f + "mixed_7a.branch0.0", 1, 1, 1, 1, 0, 0);
+        R.bconv(a, f + "mixed_7a.branch0.1", 3, 3, 2, 2, 0, 0, &s0);
+        a = R.bconv(x, f + "mixed_7a.branch1.0", 1, 1, 1, 1, 0, 0);
+        R.bconv(a, f + "mixed_7a.branch1.1", 3, 3, 2, 2, 0, 0, &s1);
+        a = R.bconv(x, f + "mixed_7a.branch2.0", 1, 1, 1, 1, 0, 0);
+        Act a2 = R.bconv(a, f + "mixed_7a.branch2.1", 3, 3, 1, 1, 1, 1);
+        R.bconv(a2, f + "mixed_7a.branch2.2", 3, 3, 2, 2, 0, 0, &s2);
+        R.pool(x, 3, 2, 0, &s3);
+        x = cat;
+    }
+    for (int i = 0; i < 5; i++) x = block8(R, x, f + "repeat_3." + std::to_string(i), 0.20f, true);
+    x = block8(R, x, f + "block8", 1.0f, false);
+    if (R.err != TRL_OK) return R.err;
+    // avgpool_1a -> last_linear (no bias) -> last_bn (folded) -> F.normalize
+    Act g = R.alloc(n, 1, 1, x.c);
+    if (R.err != TRL_OK) return R.err;
+    TRL_CHECK(trl_launch_gap(x.p, n, x.h * x.w, x.c, g.p, s));
+    Act e = R.conv(g, trl_w(c, f + "last_linear.w"), nullptr, trl_v(c, f + "last_bn.scale"), trl_v(c, f + "last_bn.shift"),
+                   nullptr, 1, 1, 1, 1, 0, 0, TRL_ACT_NONE, nullptr, nullptr, 0.f);
+    if (R.err != TRL_OK) return R.err;
+    return trl_launch_l2norm512(e.p, d_valid, n, d_emb, s);
+}
+
+// RNet: d_out6[n][6] = {logit0, logit1, reg0..3}
+int trl_run_rnet(trl_ctx* c, const float* d_crops, int n, float* d_out6, hipStream_t s) {
+    if (n <= 0) return TRL_OK;
+    Runner R{c, s};
+    Act x0; x0.p = const_cast<float*>(d_crops); x0.n = n; x0.h = 24; x0.w = 24; x0.c = 3; x0.ld = 3; x0.coff = 0;
+    Act x = R.mconv(x0, "rnet", "conv1", "prelu1", 3);
+    x = R.pool(x, 3, 2, 1);
+    x = R.mconv(x, "rnet", "conv2", "prelu2", 3);
+    x = R.pool(x, 3, 2, 1);
+    x = R.mconv(x, "rnet", "conv3", "prelu3", 2);
+    x = R.mconv(x, "rnet", "dense4", "prelu4", 3);
+    Act out; out.p = d_out6; out.n = n; out.h = 1; out.w = 1; out.c = 6; out.ld = 6; out.coff = 0;
+    R.conv(x, trl_w(c, "rnet.heads.w"), trl_v(c, "rnet.heads.b"), nullptr, nullptr, nullptr, 1, 1, 1, 1, 0, 0,
+           TRL_ACT_NONE, &out, nullptr, 0.f);
+    return R.err;
+}
+
+// ONet: d_out16[n][16] = {logit0, logit1, reg0..3, landmarks0..9}
+int trl_run_onet(trl_ctx* c, const float* d_crops, int n, float* d_out16, hipStream_t s) {
+    if (n <= 0) return TRL_OK;
+    Runner R{c, s};
+    Act x0; x0.p = const_cast<float*>(d_crops); x0.n = n; x0.h = 48; x0.w = 48; x0.c = 3; x0.ld = 3; x0.coff = 0;
+    Act x = R.mconv(x0, "onet", "conv1", "prelu1", 3);
+    x = R.pool(x, 3, 2, 1);
+    x = R.mconv(x, "onet", "conv2", "prelu2", 3);
+    x = R.pool(x, 3, 2, 1);
+    x = R.mconv(x, "onet", "conv3", "prelu3", 3);
+    x = R.pool(x, 2, 2, 1);
+    x = R.mconv(x, "onet", "conv4", "prelu4", 2);
+    x = R.mconv(x, "onet", "dense5", "prelu5", 3);
+    Act out; out.p = d_out16; out.n = n; out.h = 1; out.w = 1; out.c = 16; out.ld = 16; out.coff = 0;
+    R.conv(x, trl_w(c, "onet.heads.w"), trl_v(c, "onet.heads.b"), nullptr, nullptr, nullptr, 1, 1, 1, 1, 0, 0,
+           TRL_ACT_NONE, &out, nullptr, 0.f);
+    return R.err;
+}
+
+size_t trl_pnet_generic_bytes(int nf, int h, int w) {
+    const size_t c1 = (size_t)(h - 2) * (w - 2) * 10, ph = (h - 2 + 1) / 2, pw = (w - 2 + 1) / 2;
+    const size_t p1 = ph * pw * 10, c2 = (ph - 2) * (pw - 2) * 16, c3 = (ph - 4) * (pw - 4) * 32;
+    return (size_t)nf * (c1 + p1 + c2 + c3) * sizeof(float) + 4096;
+}
+
+// PNet through the generic layer kernels (validation path / fallback): heads [nf][oh][ow][6]
+int trl_run_pnet_generic(trl_ctx* c, const float* d_level, int nf, int h, int w, float* d_heads, hipStream_t s) {
+    Runner R{c, s};
+    Act x0; x0.p = const_cast<float*>(d_level); x0.n = nf; x0.h = h; x0.w = w; x0.c = 3; x0.ld = 3; x0.coff = 0;
+    Act x = R.mconv(x0, "pnet", "conv1", "prelu1", 3);
+    x = R.pool(x, 2, 2, 1);
+    x = R.mconv(x, "pnet", "conv2", "prelu2", 3);
+    x = R.mconv(x, "pnet", "conv3", "prelu3", 3);
+    Act out; out.p = d_heads; out.n = nf; out.h = x.h; out.w = x.w; out.c = 6; out.ld = 6; out.coff = 0;
+    R.conv(x, trl_w(c, "pnet.heads.w"), trl_v(c, "pnet.heads.b"), nullptr, nullptr, nullptr, 1, 1, 1, 1, 0, 0,
+           TRL_ACT_NONE, &out, nullptr, 0.f);
+    return R.err;
+}

@@ -1,0 +1,178 @@
+"""Persistent device context of the hot path: weights uploaded once, workspaces reused.
+
+The reference rebuilds ``MTCNN()`` and ``InceptionResnetV1(pretrained="vggface2")`` on every
+``run()`` call (server/model.py:18-19); here an :class:`Engine` is created once per GPU and shared
+by :class:`mtcnn.MTCNN`, :class:`inception_resnet_v1.InceptionResnetV1` and :func:`model.run`.
+PyTorch is used for device memory and streams only; every kernel is in libtruely_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as _weights
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    def __init__(self, blob: bytes | None = None, device: int | None = None, pnet_mode: int | None = None,
+                 cap_level: int | None = None, cap_frame: int | None = None, min_face_size: int = 20,
+                 thresholds=(0.6, 0.7, 0.7), factor: float = 0.709, max_faces: int = 64):
+        if not torch.cuda.is_available():
+            raise RuntimeError("truely_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.lib = _lib.load()
+        cfg = _lib.TrlConfig()
+        _lib.check(self.lib.trl_default_config(C.byref(cfg)))
+        cfg.device = torch.cuda.current_device() if device is None else int(device)
+        cfg.min_face_size = int(min_face_size)
+        cfg.thr0, cfg.thr1, cfg.thr2 = (float(t) for t in thresholds)
+        cfg.factor = float(factor)
+        cfg.max_faces = int(max_faces)
+        if pnet_mode is not None:
+            cfg.pnet_mode = int(pnet_mode)
+        if cap_level:
+            cfg.cap_level = int(cap_level)
+        if cap_frame:
+            cfg.cap_frame = int(cap_frame)
+        self.cfg = cfg
+        self.device = torch.device("cuda", cfg.device)
+        h = C.c_void_p()
+        _lib.check(self.lib.trl_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        if blob is None:
+            blob = _weights.synthetic_blob(0)   # no checkpoints exist offline
+        _lib.check(self.lib.trl_load_weights(self._h, blob, len(blob)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.trl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _frames(self, frames) -> torch.Tensor:
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+            raise ValueError("frames must be uint8 (n, H, W, 3) BGR")
+        return frames.to(self.device, non_blocking=True).contiguous()
+
+    # server/model.py:47 for a batch
+    def mtcnn_detect(self, frames):
+        fr = self._frames(frames)
+        n, H, W, _ = fr.shape
+        mf = self.cfg.max_faces
+        boxes = torch.empty((n, mf, 4), dtype=torch.float32, device=self.device)
+        probs = torch.empty((n, mf), dtype=torch.float32, device=self.device)
+        counts = torch.empty((n,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.trl_mtcnn_detect(self._h, _ptr(fr), n, H, W, _ptr(boxes), _ptr(probs), _ptr(counts), self._stream()))
+        return boxes, probs, counts
+
+    # server/model.py:59 for a batch; faces f32 (n, h, w, 3) NHWC in [0,1]
+    def facenet_embed(self, faces: torch.Tensor) -> torch.Tensor:
+        faces = faces.to(self.device, torch.float32).contiguous()
+        n, h, w, _ = faces.shape
+        emb = torch.empty((n, 512), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.trl_facenet_embed(self._h, _ptr(faces), n, h, w, _ptr(emb), self._stream()))
+        return emb
+
+    # server/model.py:47-59 for a batch of sampled frames
+    def detect_embed(self, frames):
+        fr = self._frames(frames)
+        n, H, W, _ = fr.shape
+        d = self.device
+        out = {"box": torch.empty((n, 4), dtype=torch.float32, device=d), "prob": torch.empty((n,), dtype=torch.float32, device=d),
+               "rect": torch.empty((n, 4), dtype=torch.int32, device=d), "valid": torch.empty((n,), dtype=torch.uint8, device=d),
+               "emb": torch.empty((n, 512), dtype=torch.float32, device=d)}
+        _lib.check(self.lib.trl_detect_embed(self._h, _ptr(fr), n, H, W, _ptr(out["box"]), _ptr(out["prob"]), _ptr(out["rect"]),
+                                             _ptr(out["valid"]), _ptr(out["emb"]), self._stream()))
+        return out
+
+    # server/model.py:60-66,86-95
+    def drift_score(self, emb: torch.Tensor, valid: torch.Tensor, frame_count: int, fps: int):
+        emb = emb.to(self.device, torch.float32).contiguous()
+        valid = valid.to(self.device, torch.uint8).contiguous()
+        n = int(valid.shape[0])
+        sims = torch.empty((n,), dtype=torch.float32, device=self.device)
+        flags = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        res = torch.zeros((4,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.trl_drift_score(self._h, _ptr(emb), _ptr(valid), n, int(frame_count), int(fps), _ptr(sims), _ptr(flags),
+                                            _ptr(res), self._stream()))
+        r = res.cpu().tolist()
+        return {"score": r[0], "run": r[1], "hits": r[2], "total": r[3], "sims": sims, "flags": flags}
+
+    # ---- inspection hooks (parity tests) ----
+    def stage_boxes(self, stage: int, frame: int, max_rows: int = 4096) -> np.ndarray:
+        buf = np.zeros((max_rows, 5), np.float32)
+        k = C.c_int()
+        _lib.check(self.lib.trl_debug_stage_boxes(self._h, stage, frame, buf.ctypes.data_as(C.c_void_p), max_rows, C.byref(k)))
+        return buf[:min(k.value, max_rows)].copy()
+
+    def level_counts(self, frame: int):
+        a = np.zeros(32, np.int32); b = np.zeros(32, np.int32)
+        L = C.c_int()
+        _lib.check(self.lib.trl_debug_level_counts(self._h, frame, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.byref(L)))
+        return a[:L.value].tolist(), b[:L.value].tolist()
+
+    def pnet_level(self, frame, level: int):
+        fr = self._frames(frame[None] if frame.ndim == 3 else frame)
+        _, H, W, _ = fr.shape
+        prob = torch.empty((H * W,), dtype=torch.float32, device=self.device)
+        reg = torch.empty((H * W * 4,), dtype=torch.float32, device=self.device)
+        oh, ow = C.c_int(), C.c_int()
+        _lib.check(self.lib.trl_debug_pnet_level(self._h, _ptr(fr), H, W, level, _ptr(prob), _ptr(reg), C.byref(oh), C.byref(ow), self._stream()))
+        k = oh.value * ow.value
+        return prob[:k].reshape(oh.value, ow.value), reg[:4 * k].reshape(oh.value, ow.value, 4)
+
+    def rnet(self, crops: torch.Tensor) -> torch.Tensor:
+        crops = crops.to(self.device, torch.float32).contiguous()
+        out = torch.empty((crops.shape[0], 6), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.trl_debug_rnet(self._h, _ptr(crops), crops.shape[0], _ptr(out), self._stream()))
+        return out
+
+    def onet(self, crops: torch.Tensor) -> torch.Tensor:
+        crops = crops.to(self.device, torch.float32).contiguous()
+        out = torch.empty((crops.shape[0], 16), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.trl_debug_onet(self._h, _ptr(crops), crops.shape[0], _ptr(out), self._stream()))
+        return out
+
+    def crop_resize(self, frames, rect: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
+        fr = self._frames(frames)
+        n, H, W, _ = fr.shape
+        rect = rect.to(self.device, torch.int32).contiguous(); valid = valid.to(self.device, torch.uint8).contiguous()
+        out = torch.empty((n, 80, 80, 3), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.trl_debug_crop_resize(self._h, _ptr(fr), n, H, W, _ptr(rect), _ptr(valid), _ptr(out), self._stream()))
+        return out
+
+    def timings(self):
+        t = (C.c_float * 3)()
+        _lib.check(self.lib.trl_debug_timings(self._h, t))
+        return {"pnet_ms": t[0], "call_ms": t[1], "pnet_launches": int(t[2])}
+
+
+_default: Engine | None = None
+
+
+def default_engine() -> Engine:
+    """Process-wide engine on the current device (synthetic weights unless TRUELY_WEIGHTS points at a TRLW blob)."""
+    global _default
+    if _default is None:
+        import os
+        path = os.environ.get("TRUELY_WEIGHTS")
+        blob = open(path, "rb").read() if path else None
+        _default = Engine(blob)
+    return _default
