@@ -28,7 +28,7 @@ int trl_default_config(trl_config* cfg) {
     cfg->cap_level = 2048;
     cfg->cap_frame = 2048;
     cfg->max_faces = 64;
-    cfg->pnet_mode = 0;
+    cfg->pnet_mode = 1;   // until the fused kernel lands
     return TRL_OK;
 }
 

@@ -48,6 +48,7 @@ class Engine:
         self._h = h
         if blob is None:
             blob = _weights.synthetic_blob(0)   # no checkpoints exist offline
+        self._blob = blob
         _lib.check(self.lib.trl_load_weights(self._h, blob, len(blob)))
 
     def close(self):
