@@ -116,9 +116,10 @@ int  trl_debug_onet(trl_ctx* ctx, const float* d_crops, int n, float* d_out, voi
 /* model.py:55-58 alone: crop rect (x0,y0,x1,y1 per frame, i32) -> f32 [n][80][80][3] in [0,1] */
 int  trl_debug_crop_resize(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
                            const int32_t* d_rect, const uint8_t* d_valid, float* d_faces, void* stream);
-/* Time (ms, HIP events on the call's stream) spent in the dominant kernels during the last
- * trl_detect_embed call: out[0]=PNet kernel(s), out[1]=whole call, out[2]=#PNet launches. */
-int  trl_debug_timings(trl_ctx* ctx, float* out3);
+/* Time (ms, HIP events on the call's stream) of the last trl_detect_embed call:
+ * out[0] = PNet kernel (fused: the one persistent launch; generic: sum over levels),
+ * out[1] = whole call, out[2] = number of PNet launches timed, out[3] = pyramid kernel. */
+int  trl_debug_timings(trl_ctx* ctx, float* out4);
 
 #ifdef __cplusplus
 }

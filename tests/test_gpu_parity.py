@@ -101,6 +101,25 @@ def test_cascade_generic_pnet_360p(engine_generic, oracle):
     assert ref["valid"].sum() >= 1
 
 
+def test_cascade_fused_pnet_small(engine, oracle):
+    _check_cascade(engine, oracle, frames_small(6, 180, 320))
+
+
+def test_cascade_fused_pnet_360p(engine, oracle):
+    _check_cascade(engine, oracle, truely_amd.synthetic.synthetic_frames(4, 360, 640, seed=11))
+
+
+def test_cascade_fused_pnet_odd_sizes(engine, oracle):
+    """Level sizes that exercise ceil-mode pooling edges and partial tiles."""
+    for (H, W, seed) in [(97, 131, 21), (200, 150, 22), (64, 333, 23)]:
+        _check_cascade(engine, oracle, truely_amd.synthetic.synthetic_frames(3, H, W, seed=seed))
+
+
+def test_cascade_fused_pnet_720p(engine, oracle):
+    out, ref = _check_cascade(engine, oracle, truely_amd.synthetic.synthetic_frames(3, 720, 1280, seed=0))
+    assert ref["valid"].sum() >= 1
+
+
 def test_crop_resize_fixed_point(engine, oracle):
     fr = frames_small(3, 180, 320)
     rects = np.array([[10, 20, 171, 150], [0, 0, 320, 180], [100, 50, 140, 93]], np.int32)   # down, down, up-sampling

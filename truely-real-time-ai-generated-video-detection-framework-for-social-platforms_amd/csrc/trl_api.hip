@@ -28,7 +28,7 @@ int trl_default_config(trl_config* cfg) {
     cfg->cap_level = 2048;
     cfg->cap_frame = 2048;
     cfg->max_faces = 64;
-    cfg->pnet_mode = 1;   // until the fused kernel lands
+    cfg->pnet_mode = 0;
     return TRL_OK;
 }
 
@@ -206,13 +206,22 @@ static int check_call(trl_ctx* c, const void* frames, int n, int H, int W) {
 }
 
 static void collect_timings(trl_ctx* c) {
-    float call_ms = 0.f, pnet_ms = 0.f;
+    float call_ms = 0.f, pnet_ms = 0.f, pyr_ms = 0.f;
     hipEventElapsedTime(&call_ms, c->ev_call0, c->ev_call1);
-    for (int i = 0; i < c->pnet_ev_used; i++) {
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, c->pnet_ev[i].first, c->pnet_ev[i].second) == hipSuccess) pnet_ms += t;
+    int launches = 0;
+    if (c->cfg.pnet_mode == 0 && c->pnet_ev_used >= 2) {
+        // pair 0 = pyramid kernel, pair 1 = the fused PNet kernel (the dominant kernel, one launch)
+        hipEventElapsedTime(&pyr_ms, c->pnet_ev[0].first, c->pnet_ev[0].second);
+        hipEventElapsedTime(&pnet_ms, c->pnet_ev[1].first, c->pnet_ev[1].second);
+        launches = 1;
+    } else {
+        for (int i = 0; i < c->pnet_ev_used; i++) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, c->pnet_ev[i].first, c->pnet_ev[i].second) == hipSuccess) pnet_ms += t;
+        }
+        launches = c->pnet_ev_used;
     }
-    c->last_ms[0] = pnet_ms; c->last_ms[1] = call_ms; c->last_ms[2] = (float)c->pnet_ev_used;
+    c->last_ms[0] = pnet_ms; c->last_ms[1] = call_ms; c->last_ms[2] = (float)launches; c->last_ms[3] = pyr_ms;
 }
 
 extern "C" {
@@ -334,9 +343,9 @@ int trl_debug_crop_resize(trl_ctx* c, const uint8_t* d_frames, int n, int H, int
     if (!c || !d_frames || !d_rect || !d_valid || !d_faces || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
     return trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, d_faces, (hipStream_t)stream);
 }
-int trl_debug_timings(trl_ctx* c, float* out3) {
-    if (!c || !out3) return TRL_ERR_INVALID;
-    out3[0] = c->last_ms[0]; out3[1] = c->last_ms[1]; out3[2] = c->last_ms[2];
+int trl_debug_timings(trl_ctx* c, float* out4) {
+    if (!c || !out4) return TRL_ERR_INVALID;
+    out4[0] = c->last_ms[0]; out4[1] = c->last_ms[1]; out4[2] = c->last_ms[2]; out4[3] = c->last_ms[3];
     return TRL_OK;
 }
 

@@ -654,19 +654,30 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         }
         TRL_CHECK(trl_ensure(c, X, mx + (4u << 20)));
     }
-    for (int l = 0; l < L; l++) {
-        const LevelGeom& g = c->lv[l];
-        if (g.oh < 1 || g.ow < 1) continue;
+    auto next_ev = [&](std::pair<hipEvent_t, hipEvent_t>*& out) -> int {
         if ((int)c->pnet_ev.size() <= c->pnet_ev_used) {
             hipEvent_t e0, e1;
             TRL_HIP(hipEventCreate(&e0)); TRL_HIP(hipEventCreate(&e1));
             c->pnet_ev.push_back({e0, e1});
         }
-        auto& ev = c->pnet_ev[c->pnet_ev_used++];
-        TRL_HIP(hipEventRecord(ev.first, s));
-        if (c->cfg.pnet_mode == 0) {
-            TRL_CHECK(trl_pnet_fused_level(c, d_frames, n, H, W, l, s));
-        } else {
+        out = &c->pnet_ev[c->pnet_ev_used++];
+        return TRL_OK;
+    };
+    if (c->cfg.pnet_mode == 0) {
+        // fused path: pyramid kernel + ONE persistent PNet launch over every (frame, level, tile)
+        TRL_CHECK(trl_ensure(c, X, trl_pnet_fused_bytes(c, n, H, W) + (1u << 20)));
+        std::pair<hipEvent_t, hipEvent_t>*pa, *pb;
+        c->pnet_ev.reserve(64);   // next_ev hands out pointers into the vector: no reallocation below
+        TRL_CHECK(next_ev(pa)); TRL_CHECK(next_ev(pb));
+        hipEvent_t ev[4] = {pa->first, pa->second, pb->first, pb->second};
+        TRL_CHECK(trl_pnet_fused_all(c, d_frames, n, H, W, ev, s));
+    } else {
+        for (int l = 0; l < L; l++) {
+            const LevelGeom& g = c->lv[l];
+            if (g.oh < 1 || g.ow < 1) continue;
+            std::pair<hipEvent_t, hipEvent_t>* pe;
+            TRL_CHECK(next_ev(pe));
+            TRL_HIP(hipEventRecord(pe->first, s));
             // generic layer path: materialise the level for a chunk of frames
             for (int f0 = 0; f0 < n; f0 += chunk[l]) {
                 const int nf = (n - f0 < chunk[l]) ? n - f0 : chunk[l];
@@ -683,8 +694,8 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
                                                                  B.lvl_cnt, B.lvl_rec, B.flags);
                 TRL_LAUNCH_CHECK();
             }
+            TRL_HIP(hipEventRecord(pe->second, s));
         }
-        TRL_HIP(hipEventRecord(ev.second, s));
     }
     const size_t sm_l = Smem::bytes(cap), sm_f = Smem::bytes(capF);
     TRL_CHECK(set_dyn_smem(k_nms_level, sm_l));

@@ -45,7 +45,7 @@ struct trl_ctx {
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pnet_ev;
     int pnet_ev_used = 0;
-    float last_ms[3] = {0, 0, 0};
+    float last_ms[4] = {0, 0, 0, 0};
 };
 
 int trl_ensure(trl_ctx* c, Arena& a, size_t bytes);   // grow (never while blocks of `a` are live)
@@ -71,4 +71,5 @@ int trl_launch_heads_to_maps(const float* d_heads, int cells, float* d_prob, flo
 int trl_compute_levels(trl_ctx* c, int H, int W);
 // fused PNet (trl_pnet.hip)
 int trl_pnet_prepare(trl_ctx* c);
-int trl_pnet_fused_level(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, int l, hipStream_t s);
+size_t trl_pnet_fused_bytes(trl_ctx* c, int n, int H, int W);
+int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipEvent_t* ev, hipStream_t s);

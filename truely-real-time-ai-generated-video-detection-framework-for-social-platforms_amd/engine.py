@@ -160,9 +160,9 @@ class Engine:
         return out
 
     def timings(self):
-        t = (C.c_float * 3)()
+        t = (C.c_float * 4)()
         _lib.check(self.lib.trl_debug_timings(self._h, t))
-        return {"pnet_ms": t[0], "call_ms": t[1], "pnet_launches": int(t[2])}
+        return {"pnet_ms": t[0], "call_ms": t[1], "pnet_launches": int(t[2]), "pyramid_ms": t[3]}
 
 
 _default: Engine | None = None
