@@ -1,0 +1,109 @@
+"""GPU tests of the drop-in API surface (MTCNN.detect, InceptionResnetV1.__call__, model.run,
+analyze_video) and of the committed golden vectors through the HIP path."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import truely_amd
+from conftest import frames_small
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "clip_*.npz"))))
+def test_hip_path_reproduces_golden(engine, path):
+    z = np.load(path)
+    n, H, W, seed = int(z["n"]), int(z["H"]), int(z["W"]), int(z["seed"])
+    fr = truely_amd.synthetic.synthetic_frames(n, H, W, seed=seed)
+    out = engine.detect_embed(fr)
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        assert np.array_equal(out[k].cpu().numpy(), z[k]), k
+    for i in range(n):
+        cand, keep = engine.level_counts(i)
+        assert cand == z[f"f{i}_cand"].tolist() and keep == z[f"f{i}_keep"].tolist()
+        for s in (1, 2, 3):
+            assert np.array_equal(engine.stage_boxes(s, i), z[f"f{i}_boxes{s}"])
+    d = engine.drift_score(out["emb"], out["valid"], n * 4, 30)
+    assert d["score"] == int(z["score"]) and np.array_equal(d["sims"].cpu().numpy(), z["sims"])
+
+
+def test_mtcnn_detect_api(engine, oracle):
+    from truely_amd.mtcnn import MTCNN
+    m = MTCNN(engine=engine)
+    fr = truely_amd.synthetic.synthetic_frames(3, 360, 640, seed=11)
+    boxes, probs = m.detect(fr[0])                      # single frame -> unbatched, like facenet-pytorch
+    rb, rp = oracle.detect(fr[0])
+    assert (boxes is None) == (rb is None)
+    if boxes is not None:
+        assert boxes.dtype == np.float32 and np.array_equal(boxes, rb) and np.array_equal(probs, rp)
+    bb, pp = m.detect(fr)                               # batch -> object arrays
+    assert len(bb) == 3
+    for i in range(3):
+        rb, rp = oracle.detect(fr[i])
+        assert (bb[i] is None) == (rb is None)
+        if rb is not None:
+            assert np.array_equal(bb[i], rb)
+    none_b, none_p = m.detect(np.full((64, 64, 3), 128, np.uint8))
+    if none_b is None:
+        assert none_p == [None]
+
+
+def test_inception_resnet_api(engine, oracle):
+    from truely_amd.inception_resnet_v1 import InceptionResnetV1
+    net = InceptionResnetV1(pretrained="vggface2", engine=engine).eval()
+    x = torch.rand(2, 3, 80, 80)                        # what to_tensor(...).unsqueeze(0) yields, batched
+    y = net(x)
+    assert y.shape == (2, 512) and y.device.type == "cpu"
+    ref = oracle.facenet(x.permute(0, 2, 3, 1).contiguous().numpy())
+    assert np.array_equal(y.numpy(), ref)
+
+
+def test_run_end_to_end_raw_container(engine, oracle, tmp_path, monkeypatch):
+    from truely_amd import engine as eng_mod, model, video_io
+    monkeypatch.setattr(eng_mod, "_default", engine)
+    H, W, fps = 180, 320, 30
+    fr = truely_amd.synthetic.synthetic_frames(40, H, W, seed=3)
+    src, dst = str(tmp_path / "in.trlv"), str(tmp_path / "out.trlv")
+    video_io.write_raw(src, fr, fps)
+    score = model.run(src, dst)
+    # oracle: sample every 4th frame, same path
+    sampled = fr[::4]
+    r = oracle.detect_embed(sampled)
+    d = oracle.drift_score(r["emb"], r["valid"], 40, fps)
+    assert score == d["score"] and 0 <= score <= 100
+    assert os.path.getsize(dst) > 0                     # server.py:612-627 requires a non-empty output
+    rd, ofps, ow, oh = video_io.open_reader(dst)
+    assert (ofps, ow, oh, rd.n) == (fps, W, H, 40)      # every frame is written (model.py:77)
+
+
+def test_analyze_video_batching_invariant(engine):
+    from truely_amd.model import analyze_video
+    fr = frames_small(10, 180, 320, seed=8)
+    a = analyze_video(fr, fps=30, engine=engine)
+    b = analyze_video(fr, fps=30, engine=engine, batch=3)    # ragged batches 3+3+3+1
+    assert a["score"] == b["score"]
+    assert torch.equal(a["emb"], b["emb"]) and torch.equal(a["valid"], b["valid"]) and torch.equal(a["sims"], b["sims"])
+
+
+def test_capacity_overflow_is_an_error(blob):
+    from truely_amd.engine import Engine
+    from truely_amd._lib import TrlError
+    small = Engine(blob, cap_level=64, cap_frame=64)
+    fr = truely_amd.synthetic.synthetic_frames(1, 720, 1280, seed=0)
+    with pytest.raises(TrlError) as e:
+        small.detect_embed(fr)
+    assert e.value.status == -4 and "overflow" in str(e.value)
+
+
+def test_bad_arguments_are_rejected(engine):
+    from truely_amd._lib import TrlError
+    with pytest.raises(ValueError):
+        engine.detect_embed(np.zeros((1, 8, 8, 4), np.uint8))
+    with pytest.raises(TrlError):
+        engine.detect_embed(np.zeros((1, 8, 8, 3), np.uint8))      # smaller than the 12x12 PNet field
+    with pytest.raises(TrlError):
+        engine.facenet_embed(torch.zeros(1, 40, 40, 3))            # too small for the stem

@@ -1,0 +1,126 @@
+"""CPU tests of the host side: weight packing, the C-ABI library's symbol table, video containers,
+sharding helpers, and model.run's error convention (server/model.py:20-34).  No GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import truely_amd
+from truely_amd import _lib, video_io, weights
+from truely_amd.distributed import shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported_by_library():
+    """Every function declared in include/truely_hip.h is exported by libtruely_hip.so (no compute)."""
+    hdr = open(os.path.join(ROOT, "include", "truely_hip.h")).read()
+    declared = set(re.findall(r"\b(trl_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r"\bT (trl_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+
+
+def test_library_loads_and_reports_abi():
+    lib = _lib.load()
+    assert lib.trl_abi_version() == 1
+    cfg = _lib.TrlConfig()
+    assert lib.trl_default_config(ctypes.byref(cfg)) == 0
+    assert (cfg.min_face_size, round(cfg.thr0, 3), round(cfg.thr1, 3), round(cfg.thr2, 3), cfg.factor) == (20, 0.6, 0.7, 0.7, 0.709)
+    # bad config is rejected with a message, not a crash
+    cfg.cap_level = 7
+    h = ctypes.c_void_p()
+    assert lib.trl_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"trl_config" in lib.trl_last_error()
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from truely_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine(b"")
+
+
+def test_weight_pack_roundtrip_and_layout(state_dicts, blob):
+    t = weights.unpack_tensors(blob)
+    pn, rn, on, fn = state_dicts
+    # conv OIHW -> [ (ky*KW+kx)*Cin + c ][ Cout ]
+    w = pn["conv2.weight"]
+    k = (1 * 3 + 2) * 10 + 7
+    assert t["pnet.conv2.w"].shape == (90, 16) and t["pnet.conv2.w"][k, 5] == w[5, 7, 1, 2]
+    # dense4: torch flatten order after permute(0,3,2,1) is (w, h, c); packed order is (h, w, c)
+    d = rn["dense4.weight"]
+    hh, ww, cc = 2, 1, 33
+    assert t["rnet.dense4.w"][(hh * 3 + ww) * 64 + cc, 9] == d[9, (ww * 3 + hh) * 64 + cc]
+    # BN fold: alpha = g / sqrt(var + 1e-3), beta = b - mean * alpha
+    g, b = fn["conv2d_1a.bn.weight"], fn["conv2d_1a.bn.bias"]
+    m, v = fn["conv2d_1a.bn.running_mean"], fn["conv2d_1a.bn.running_var"]
+    a = (g * (np.float32(1) / np.sqrt(v + np.float32(1e-3)))).astype(np.float32)
+    assert np.array_equal(t["facenet.conv2d_1a.scale"], a)
+    assert np.array_equal(t["facenet.conv2d_1a.shift"], (b - m * a).astype(np.float32))
+    assert t["facenet.last_linear.w"].shape == (1792, 512)
+    assert weights.pack_tensors(t) == blob
+    assert len(weights.facenet_basic_convs()) == 111 and len(weights.facenet_proj_convs()) == 21   # 132 convs
+
+
+def test_synthetic_frames_are_deterministic():
+    a = truely_amd.synthetic.synthetic_frames(2, 90, 160, seed=5)
+    b = truely_amd.synthetic.synthetic_frames(2, 90, 160, seed=5)
+    assert a.dtype == np.uint8 and a.shape == (2, 90, 160, 3) and np.array_equal(a, b)
+    assert not np.array_equal(a, truely_amd.synthetic.synthetic_frames(2, 90, 160, seed=6))
+
+
+def test_raw_video_container_roundtrip(tmp_path):
+    fr = truely_amd.synthetic.synthetic_frames(5, 48, 64, seed=1)
+    p = str(tmp_path / "clip.trlv")
+    video_io.write_raw(p, fr, 29.97)
+    rd, fps, w, h = video_io.open_reader(p)
+    assert (fps, w, h) == (29, 64, 48)       # int(cap.get(CAP_PROP_FPS)) truncates (model.py:28)
+    got = []
+    while True:
+        ok, f = rd.read()
+        if not ok:
+            break
+        got.append(f)
+    assert np.array_equal(np.stack(got), fr)
+
+
+def test_draw_box_stays_inside_frame():
+    img = np.zeros((40, 50, 3), np.uint8)
+    video_io.draw_box(img, -5, 3, 60, 38, (0, 255, 0), 2)
+    assert img[:, :, 1].max() == 255 and img.shape == (40, 50, 3)
+
+
+def test_run_error_convention(tmp_path, capsys):
+    """Missing / empty / unreadable inputs return 0 and print, like server/model.py:20-26."""
+    from truely_amd import model
+    assert model.run(str(tmp_path / "nope.mp4"), str(tmp_path / "o.mp4")) == 0
+    empty = tmp_path / "empty.mp4"; empty.write_bytes(b"")
+    assert model.run(str(empty), str(tmp_path / "o.mp4")) == 0
+    junk = tmp_path / "junk.mp4"; junk.write_bytes(b"not a video at all" * 10)
+    assert model.run(str(junk), str(tmp_path / "o.mp4")) == 0
+    out = capsys.readouterr().out
+    assert "doesn't exist or is empty" in out and "couldn't open" in out
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 7, 240, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_flop_model_matches_survey():
+    import bench
+    assert abs(bench.pnet_macs(720, 1280) / 1e6 - 1171.4) < 0.1
+    assert abs(bench.pnet_macs(360, 640) / 1e6 - 281.2) < 0.1

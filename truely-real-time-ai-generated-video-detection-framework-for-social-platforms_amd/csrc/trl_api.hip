@@ -57,6 +57,7 @@ int trl_destroy(trl_ctx* c) {
     if (c->wdev) hipFree(c->wdev);
     if (c->arena.base) hipFree(c->arena.base);
     if (c->scratch.base) hipFree(c->scratch.base);
+    if (c->pyr_tab) hipFree(c->pyr_tab);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->ev_call0) hipEventDestroy(c->ev_call0);
     if (c->ev_call1) hipEventDestroy(c->ev_call1);

@@ -42,11 +42,15 @@ struct PLevel {
     int h, w, oh, ow;        // level size, PNet map size
     int tiles_x, tile0;      // tiles per row, first tile index of the level inside a frame
     int pix0;                // float4 offset of the level inside a frame's pyramid
+    int pix_pad;             // h*w rounded up to 64 (pyramid slots of the level)
+    int gshift, work0;       // pyramid kernel: log2(lanes per pixel), first thread of the level inside a frame
+    int ytab0, xtab0;        // offsets of the level's row / column bin-edge tables
     float scale;
 };
 struct PnetArgs {
     const float4* pyr; long long pyr_stride;   // float4 per frame
     int n_frames, L, tiles_per_frame, H, W;
+    long long work_per_frame;                  // pyramid kernel threads per frame
     PLevel lv[16];
     const float *w1, *w2, *w3, *wh;            // [Kpad][32] zero padded
     const float *b1, *b2, *b3, *bh, *s1, *s2, *s3;
@@ -55,52 +59,84 @@ struct PnetArgs {
 };
 
 // ---- pyramid -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ frames, PnetArgs a, float4* __restrict__ pyr) {
-    const long long per_frame = a.pyr_stride;
-    const long long total = per_frame * a.n_frames;
+// One LANE GROUP of G lanes per output pixel (G = 1, 4, 16 or 64 by level: coarse levels average
+// thousands of source bytes per pixel, so their bins are split across lanes and summed with xor
+// shuffles -- integer sums, exact in any order).  Bytes are fetched as aligned dwords; the three
+// channel sums of a dword are three v_dot4_u32_u8 against 0/1 byte masks selected by the dword's
+// phase (byte offset mod 3) inside the BGR span.
+__device__ __forceinline__ void dword_sums(unsigned v, int rel, int nbytes, unsigned& s0, unsigned& s1, unsigned& s2) {
+    // rel = byte offset of this dword relative to the first byte of the span (-3 .. nbytes-1)
+    const int lo = rel < 0 ? -rel : 0;
+    const int hi = (nbytes - rel) < 4 ? (nbytes - rel) : 4;
+    const unsigned vm = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+    v &= vm;
+    const int phase = (rel + 3) % 3;   // channel of byte 0 of the dword
+    const unsigned m0 = phase == 0 ? 0x01000001u : (phase == 1 ? 0x00010000u : 0x00000100u);
+    const unsigned m1 = phase == 0 ? 0x00000100u : (phase == 1 ? 0x01000001u : 0x00010000u);
+    const unsigned m2 = phase == 0 ? 0x00010000u : (phase == 1 ? 0x00000100u : 0x01000001u);
+    s0 = __builtin_amdgcn_udot4(v, m0, s0, false);
+    s1 = __builtin_amdgcn_udot4(v, m1, s1, false);
+    s2 = __builtin_amdgcn_udot4(v, m2, s2, false);
+}
+
+// Bin edges are precomputed on the host (one packed (start | end<<16) word per output row / column of
+// every level): the kernel does no 64-bit or repeated integer division.  grid = (blocks, frames).
+__global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ frames, PnetArgs a, const uint32_t* __restrict__ tab,
+                                                 float4* __restrict__ pyr) {
+    const int per_frame = (int)a.work_per_frame;           // threads per frame, multiple of 64
+    const int f = blockIdx.y;
     const uint32_t* base32 = reinterpret_cast<const uint32_t*>(frames);
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int f = (int)(idx / per_frame);
-        const int p = (int)(idx - (long long)f * per_frame);
+    const long long fbase = (long long)f * a.H * a.W * 3;
+    const int row_bytes = a.W * 3;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < per_frame; p += gridDim.x * blockDim.x) {
         int l = 0;
-        while (l + 1 < a.L && p >= a.lv[l + 1].pix0) l++;
-        const int h = a.lv[l].h, w = a.lv[l].w;
-        const int q = p - a.lv[l].pix0;
-        if (q >= h * w) { pyr[idx] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }   // alignment padding between levels
-        const int oy = q / w, ox = q - oy * w;
-        const int ys = (int)(((long long)oy * a.H) / h), ye = (int)((((long long)oy + 1) * a.H + h - 1) / h);
-        const int xs = (int)(((long long)ox * a.W) / w), xe = (int)((((long long)ox + 1) * a.W + w - 1) / w);
-        const long long fbase = (long long)f * a.H * a.W * 3;
-        const int nbytes = (xe - xs) * 3;
+        while (l + 1 < a.L && p >= a.lv[l + 1].work0) l++;   // wave-uniform: level boundaries are multiples of 64
+        const PLevel& g = a.lv[l];
+        const int w = g.w, gsh = g.gshift, G = 1 << gsh;
+        const int q = p - g.work0;
+        const int pixel = q >> gsh, sub = q & (G - 1);
+        const bool valid = pixel < g.h * w;
         unsigned s0 = 0, s1 = 0, s2 = 0;
-        for (int y = ys; y < ye; y++) {
-            const long long o = fbase + ((long long)y * a.W + xs) * 3;   // first byte of the span
-            long long al = o & ~3ll;
-            int rel = (int)(al - o);                                      // -3..0
-            // channel of byte j of this dword = (rel + j) mod 3 ; phase = rel mod 3 in {0,1,2}
-            int phase = ((rel % 3) + 3) % 3;
-            unsigned m0 = phase == 0 ? 0x01000001u : (phase == 1 ? 0x00010000u : 0x00000100u);
-            unsigned m1 = phase == 0 ? 0x00000100u : (phase == 1 ? 0x01000001u : 0x00010000u);
-            unsigned m2 = phase == 0 ? 0x00010000u : (phase == 1 ? 0x00000100u : 0x01000001u);
-            for (; rel < nbytes; rel += 4, al += 4) {
-                unsigned v = base32[al >> 2];
-                const int lo = rel < 0 ? -rel : 0;
-                const int hi = (nbytes - rel) < 4 ? (nbytes - rel) : 4;
-                unsigned vm = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
-                v &= vm;
-                s0 = __builtin_amdgcn_udot4(v, m0, s0, false);
-                s1 = __builtin_amdgcn_udot4(v, m1, s1, false);
-                s2 = __builtin_amdgcn_udot4(v, m2, s2, false);
-                const unsigned t = m0; m0 = m2; m2 = m1; m1 = t;   // next dword: phase + 1 (4 mod 3)
+        int kh = 1, kw = 1;
+        if (valid) {
+            const int oy = pixel / w, ox = pixel - oy * w;
+            const uint32_t ty = tab[g.ytab0 + oy], tx = tab[g.xtab0 + ox];
+            const int ys = ty & 0xFFFF, ye = ty >> 16, xs = tx & 0xFFFF, xe = tx >> 16;
+            kh = ye - ys; kw = xe - xs;
+            const int nbytes = kw * 3;
+            const long long o0 = fbase + (long long)ys * row_bytes + xs * 3;   // first byte of the bin
+            if (G == 1) {
+                long long o = o0;
+                for (int y = 0; y < kh; y++, o += row_bytes) {
+                    long long al = o & ~3ll;
+                    for (int rel = (int)(al - o); rel < nbytes; rel += 4, al += 4) dword_sums(base32[al >> 2], rel, nbytes, s0, s1, s2);
+                }
+            } else {
+                const int ndw = (nbytes + 6) >> 2;            // dwords per row for the worst alignment
+                int row = 0, d = sub;
+                while (d >= ndw) { d -= ndw; row++; }
+                while (row < kh) {
+                    const long long o = o0 + (long long)row * row_bytes;
+                    const long long al = (o & ~3ll) + 4 * d;
+                    const int rel = (int)(al - o);
+                    if (rel < nbytes) dword_sums(base32[al >> 2], rel, nbytes, s0, s1, s2);
+                    d += G;
+                    while (d >= ndw) { d -= ndw; row++; }
+                }
             }
         }
-        const float kh = (float)(ye - ys), kw = (float)(xe - xs);
-        float4 o4;
-        o4.x = ((float)s0 / kh / kw - 127.5f) * 0.0078125f;
-        o4.y = ((float)s1 / kh / kw - 127.5f) * 0.0078125f;
-        o4.z = ((float)s2 / kh / kw - 127.5f) * 0.0078125f;
-        o4.w = 0.f;
-        pyr[idx] = o4;
+        for (int off = G >> 1; off >= 1; off >>= 1) {
+            s0 += __shfl_xor((int)s0, off, 64); s1 += __shfl_xor((int)s1, off, 64); s2 += __shfl_xor((int)s2, off, 64);
+        }
+        if (sub == 0 && pixel < g.pix_pad) {
+            const float fkh = (float)kh, fkw = (float)kw;
+            float4 o4;
+            o4.x = valid ? ((float)s0 / fkh / fkw - 127.5f) * 0.0078125f : 0.f;
+            o4.y = valid ? ((float)s1 / fkh / fkw - 127.5f) * 0.0078125f : 0.f;
+            o4.z = valid ? ((float)s2 / fkh / fkw - 127.5f) * 0.0078125f : 0.f;
+            o4.w = 0.f;
+            pyr[(long long)f * a.pyr_stride + g.pix0 + pixel] = o4;
+        }
     }
 }
 
@@ -338,11 +374,11 @@ int trl_pnet_prepare(trl_ctx* c) {
     return TRL_OK;
 }
 
-static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a) {
+static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<uint32_t>* tab = nullptr) {
     const int L = trl_compute_levels(c, H, W);
     if (L > 16) { trl_set_error("more than 16 pyramid levels"); return TRL_ERR_INVALID; }
     a.n_frames = n; a.L = L; a.H = H; a.W = W;
-    int tiles = 0; long long pix = 0;
+    int tiles = 0, ntab = 0; long long pix = 0, work = 0;
     for (int l = 0; l < L; l++) {
         const LevelGeom& g = c->lv[l];
         PLevel& p = a.lv[l];
@@ -351,11 +387,26 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a) {
         p.tile0 = tiles;
         tiles += p.tiles_x * ((g.oh + TS - 1) / TS);
         p.pix0 = (int)pix;
-        pix += ((long long)g.h * g.w + 15) & ~15ll;
+        p.pix_pad = (int)(((long long)g.h * g.w + 63) & ~63ll);
+        pix += p.pix_pad;
+        // lanes per output pixel: keep a lane's share of the bin near <= 32 dwords
+        const int kh = (H + g.h - 1) / g.h + 1, ndw = (((W + g.w - 1) / g.w + 1) * 3 + 6) / 4;
+        const int dwords = kh * ndw;
+        p.gshift = dwords <= 40 ? 0 : (dwords <= 160 ? 2 : (dwords <= 640 ? 4 : 6));
+        p.work0 = (int)work;
+        work += (long long)p.pix_pad << p.gshift;
+        // adaptive_avg_pool2d bin edges: [floor(i*in/out), ceil((i+1)*in/out))
+        p.ytab0 = ntab; ntab += g.h;
+        p.xtab0 = ntab; ntab += g.w;
+        if (tab) {
+            for (int i = 0; i < g.h; i++) tab->push_back((uint32_t)(((long long)i * H) / g.h) | ((uint32_t)((((long long)i + 1) * H + g.h - 1) / g.h) << 16));
+            for (int i = 0; i < g.w; i++) tab->push_back((uint32_t)(((long long)i * W) / g.w) | ((uint32_t)((((long long)i + 1) * W + g.w - 1) / g.w) << 16));
+        }
         p.scale = (float)g.scale;
     }
     a.tiles_per_frame = tiles;
     a.pyr_stride = pix;
+    a.work_per_frame = work;
     a.w1 = trl_w(c, "pnet.conv1.w")->p; a.w2 = trl_w(c, "pnet.conv2.w")->p; a.w3 = trl_w(c, "pnet.conv3.w")->p; a.wh = trl_w(c, "pnet.heads.w")->p;
     a.b1 = trl_v(c, "pnet.conv1.b")->p; a.b2 = trl_v(c, "pnet.conv2.b")->p; a.b3 = trl_v(c, "pnet.conv3.b")->p; a.bh = trl_v(c, "pnet.heads.b")->p;
     a.s1 = trl_v(c, "pnet.prelu1")->p; a.s2 = trl_v(c, "pnet.prelu2")->p; a.s3 = trl_v(c, "pnet.prelu3")->p;
@@ -374,16 +425,26 @@ size_t trl_pnet_fused_bytes(trl_ctx* c, int n, int H, int W) {
 // ev[0..1] bracket the pyramid kernel, ev[2..3] the fused kernel (HIP events on the same stream).
 int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipEvent_t* ev, hipStream_t s) {
     if (((uintptr_t)d_frames & 3) != 0) { trl_set_error("frame buffer must be 4-byte aligned"); return TRL_ERR_INVALID; }
+    if (H > 16383 || W > 16383) { trl_set_error("frame larger than 16383 px"); return TRL_ERR_INVALID; }
     PnetArgs a;
-    TRL_CHECK(fill_args(c, n, H, W, a));
+    std::vector<uint32_t> tab;
+    const bool new_shape = (c->pyr_tab == nullptr || c->pyr_tab_H != H || c->pyr_tab_W != W);
+    TRL_CHECK(fill_args(c, n, H, W, a, new_shape ? &tab : nullptr));
+    if (new_shape) {   // bin-edge tables depend on (H, W) only: built once per frame shape
+        TRL_HIP(hipStreamSynchronize(s));
+        if (c->pyr_tab) TRL_HIP(hipFree(c->pyr_tab));
+        c->pyr_tab = nullptr;
+        TRL_HIP(hipMalloc((void**)&c->pyr_tab, tab.size() * 4 + 64));
+        TRL_HIP(hipMemcpy(c->pyr_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        c->pyr_tab_H = H; c->pyr_tab_W = W;
+    }
     float4* pyr = (float4*)c->scratch.alloc((size_t)a.pyr_stride * n * sizeof(float4));
     if (!pyr) { trl_set_error("pyramid workspace"); return TRL_ERR_STATE; }
     a.pyr = pyr;
-    const long long total = a.pyr_stride * n;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    int blocks = (int)((a.work_per_frame + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
     if (ev) TRL_HIP(hipEventRecord(ev[0], s));
-    k_pyramid<<<(unsigned)blocks, 256, 0, s>>>(d_frames, a, pyr);
+    k_pyramid<<<dim3(blocks, n), 256, 0, s>>>(d_frames, a, c->pyr_tab, pyr);
     TRL_LAUNCH_CHECK();
     if (ev) { TRL_HIP(hipEventRecord(ev[1], s)); TRL_HIP(hipEventRecord(ev[2], s)); }
     const int total_tiles = a.tiles_per_frame * n;

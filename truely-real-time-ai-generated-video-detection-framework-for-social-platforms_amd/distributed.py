@@ -33,8 +33,9 @@ def allgather_embeddings(emb: torch.Tensor, valid: torch.Tensor, counts=None, gr
     pay = torch.zeros((m, 513), dtype=torch.float32, device=emb.device)
     pay[:emb.shape[0], :512] = emb
     pay[:emb.shape[0], 512] = valid.to(torch.float32)
-    out = torch.empty((world, m, 513), dtype=torch.float32, device=emb.device)
+    out = torch.empty((world * m, 513), dtype=torch.float32, device=emb.device)
     dist.all_gather_into_tensor(out, pay, group=group)
+    out = out.view(world, m, 513)
     rows = torch.cat([out[r, :sizes[r]] for r in range(world)])
     return rows[:, :512].contiguous(), rows[:, 512].to(torch.uint8).contiguous()
 
