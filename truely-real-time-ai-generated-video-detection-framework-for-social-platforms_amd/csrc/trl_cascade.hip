@@ -725,11 +725,10 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         for (int t0 = 0; t0 < T2; t0 += CH) {
             const int nc = (T2 - t0 < CH) ? T2 - t0 : CH;
             X.off = mk;
-            float* crops = (float*)X.alloc((size_t)nc * 24 * 24 * 3 * 4);
-            if (!crops || !out6) { trl_set_error("rnet workspace"); return TRL_ERR_STATE; }
-            k_crop_resample<<<nc, 256, 0, s>>>(d_frames, H, W, 24, capF, B.s1_box, B.map_frame, B.map_local, t0, crops);
-            TRL_LAUNCH_CHECK();
-            TRL_CHECK(trl_run_rnet(c, crops, nc, out6 + (size_t)t0 * 6, s));
+            float* pool1 = (float*)X.alloc((size_t)nc * 11 * 11 * 28 * 4);
+            if (!pool1 || !out6) { trl_set_error("rnet workspace"); return TRL_ERR_STATE; }
+            TRL_CHECK(trl_launch_rnet_front(c, d_frames, H, W, B.s1_box, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
+            TRL_CHECK(trl_run_rnet_tail(c, pool1, nc, out6 + (size_t)t0 * 6, s));
         }
     }
     k_stage2_post<<<n, 256, sm_f, s>>>(capF, W, H, c->cfg.thr1, B.n1, B.s1_box, B.off2, out6, B.n2, B.s2_box);
@@ -753,11 +752,10 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         for (int t0 = 0; t0 < T3; t0 += CH) {
             const int nc = (T3 - t0 < CH) ? T3 - t0 : CH;
             X.off = mk;
-            float* crops = (float*)X.alloc((size_t)nc * 48 * 48 * 3 * 4);
-            if (!crops || !out16) { trl_set_error("onet workspace"); return TRL_ERR_STATE; }
-            k_crop_resample<<<nc, 256, 0, s>>>(d_frames, H, W, 48, capF, B.s2_box, B.map_frame, B.map_local, t0, crops);
-            TRL_LAUNCH_CHECK();
-            TRL_CHECK(trl_run_onet(c, crops, nc, out16 + (size_t)t0 * 16, s));
+            float* pool1 = (float*)X.alloc((size_t)nc * 23 * 23 * 32 * 4);
+            if (!pool1 || !out16) { trl_set_error("onet workspace"); return TRL_ERR_STATE; }
+            TRL_CHECK(trl_launch_onet_front(c, d_frames, H, W, B.s2_box, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
+            TRL_CHECK(trl_run_onet_tail(c, pool1, nc, out16 + (size_t)t0 * 16, s));
         }
     }
     k_stage3_post<<<n, 256, sm_f, s>>>(capF, c->cfg.thr2, B.n2, B.s2_box, B.off3, out16, B.n3, B.s3_box, B.s3_pts);

@@ -58,6 +58,10 @@ const DevV* trl_v(trl_ctx* c, const std::string& name);
 int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const uint8_t* d_valid, float* d_emb, hipStream_t s);
 int trl_run_rnet(trl_ctx* c, const float* d_crops, int n, float* d_out6, hipStream_t s);
 int trl_run_onet(trl_ctx* c, const float* d_crops, int n, float* d_out16, hipStream_t s);
+int trl_run_rnet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out6, hipStream_t s);
+int trl_run_onet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out16, hipStream_t s);
+int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, int t0, int nc, float* d_pool, hipStream_t s);
+int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, int t0, int nc, float* d_pool, hipStream_t s);
 // PNet on one materialised level for nf frames: heads [nf][oh][ow][6]
 int trl_run_pnet_generic(trl_ctx* c, const float* d_level, int nf, int h, int w, float* d_heads, hipStream_t s);
 size_t trl_pnet_generic_bytes(int nf, int h, int w);

@@ -1,0 +1,217 @@
+// trl_front.hip -- fused front end of R-Net / O-Net for gfx950 (detect_face stages 2 and 3):
+//   crop [y-1:ey, x-1:ex] of the u8 frame -> imresample to SxS -> (v-127.5)*0.0078125
+//   -> conv1 3x3 (3->28 / 3->32) + PReLU -> MaxPool(3, 2, ceil_mode)            (one workgroup per candidate)
+// The conv1 activation (54 KB / 271 KB per candidate) never leaves LDS: only the pooled map is written,
+// which removes ~7.6 GB of HBM traffic per 256-frame batch.  conv1 runs on v_mfma_f32_16x16x4_f32 with the
+// weights in registers, k ascending from the bias: bit-identical to the oracle's conv2d chain.
+#include "trl_ctx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ void pad_box(const float* b, int W, int H, int& y, int& ey, int& x, int& ex) {
+    const int bx = (int)truncf(b[0]), by = (int)truncf(b[1]), bex = (int)truncf(b[2]), bey = (int)truncf(b[3]);
+    x = bx < 1 ? 1 : bx;
+    y = by < 1 ? 1 : by;
+    ex = bex > W ? W : bex;
+    ey = bey > H ? H : bey;
+}
+
+template <int S, int C1, int CLD, int R>
+__global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__ frames, int nframes, int H, int W, int capF,
+                                                     const float* __restrict__ boxes, const int32_t* __restrict__ map_frame,
+                                                     const int32_t* __restrict__ map_local, int t0, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ s1,
+                                                     float* __restrict__ out) {
+    constexpr int CW = S - 2;                        // conv1 output side
+    constexpr int P = (CW - 3 + 1) / 2 + 1;          // MaxPool(3,2,ceil) output side (11 / 23)
+    constexpr int SR = 2 * R + 1;                    // conv1 rows per strip
+    constexpr int IN_N = S * S * 3;
+    __shared__ __attribute__((aligned(16))) float in_s[IN_N + 128];
+    __shared__ __attribute__((aligned(16))) float c1_s[SR * CW * CLD];
+    // per-wave column-sum strip (aliases c1_s, which is dead during the crop)
+    constexpr int COLCAP = ((SR * CW * CLD - 16) / 4 < 2048 ? (SR * CW * CLD - 16) / 4 : 2048) & ~3;
+    static_assert(COLCAP >= 1024, "column strip too small");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int t = t0 + blockIdx.x;
+
+    // ---- crop + area resample + normalise -> in_s [S][S][3] ----------------------------------------------
+    // Each WAVE owns output rows oy = wave, wave+4, ...: (1) column sums of the bin's source rows, lanes along
+    // the row (coalesced aligned dwords re-aligned with v_alignbyte, four byte-columns per lane) into a
+    // per-wave LDS strip, (2) horizontal bins from the strip.  Integer sums: exact in any order.  No block barrier.
+    {
+        const int f = map_frame[t], i = map_local[t];
+        int y, ey, x, ex;
+        pad_box(boxes + ((size_t)f * capF + i) * 5, W, H, y, ey, x, ex);
+        const int y0 = y - 1, x0 = x - 1, ih = ey - y0, iw = ex - x0;
+        const uint32_t* base32 = reinterpret_cast<const uint32_t*>(frames);
+        const long long last_dw = ((long long)nframes * H * W * 3 - 1) >> 2;   // last dword holding frame bytes
+        const long long fbyte0 = (long long)f * H * W * 3;
+        unsigned* colbuf = reinterpret_cast<unsigned*>(c1_s) + wave * COLCAP;
+        if (ih <= 3 * S && iw <= 3 * S) {
+            // small boxes (bins of at most 4x4 pixels): one thread per output pixel, all loads independent
+            const uint8_t* fp = frames + fbyte0;
+            for (int p = tid; p < S * S; p += 256) {
+                const int oy = p / S, ox = p - oy * S;
+                const int ys = (oy * ih) / S, ye = ((oy + 1) * ih + S - 1) / S;
+                const int xs = (ox * iw) / S, xe = ((ox + 1) * iw + S - 1) / S;
+                unsigned a0 = 0, a1 = 0, a2 = 0;
+                for (int yy = ys; yy < ye; yy++) {
+                    const uint8_t* q = fp + ((size_t)(y0 + yy) * W + x0 + xs) * 3;
+                    for (int xx = xs; xx < xe; xx++, q += 3) { a0 += q[0]; a1 += q[1]; a2 += q[2]; }
+                }
+                const float kh = (float)(ye - ys), kw = (float)(xe - xs);
+                in_s[3 * p + 0] = ((float)a0 / kh / kw - 127.5f) * 0.0078125f;
+                in_s[3 * p + 1] = ((float)a1 / kh / kw - 127.5f) * 0.0078125f;
+                in_s[3 * p + 2] = ((float)a2 / kh / kw - 127.5f) * 0.0078125f;
+            }
+        } else
+        for (int oy = wave; oy < S; oy += 4) {
+            const int ys = (oy * ih) / S, ye = ((oy + 1) * ih + S - 1) / S;
+            const float kh = (float)(ye - ys);
+            int oxa = 0;
+            while (oxa < S) {
+                // segment of output columns whose source span fits the strip
+                const int xsa = (oxa * iw) / S;
+                int oxb = oxa + 1;
+                while (oxb < S && (((oxb + 1) * iw + S - 1) / S - xsa) * 3 <= COLCAP) oxb++;
+                const int xeb = (oxb * iw + S - 1) / S;
+                const int seg_bytes = (xeb - xsa) * 3;
+                for (int c0 = 0; c0 < seg_bytes; c0 += 256) {
+                    const int b = c0 + 4 * lane;
+                    if (b < seg_bytes) {
+                        unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                        long long o = fbyte0 + ((long long)(y0 + ys) * W + x0 + xsa) * 3 + b;
+#pragma unroll 4
+                        for (int yy = ys; yy < ye; yy++, o += (long long)W * 3) {
+                            const long long dw = o >> 2;
+                            const unsigned w0 = base32[dw];
+                            const unsigned w1 = base32[dw < last_dw ? dw + 1 : last_dw];
+                            const unsigned v = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)(o & 3));
+                            s0 += v & 0xFFu; s1 += (v >> 8) & 0xFFu; s2 += (v >> 16) & 0xFFu; s3 += v >> 24;
+                        }
+                        colbuf[b] = s0; colbuf[b + 1] = s1; colbuf[b + 2] = s2; colbuf[b + 3] = s3;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int idx = lane; idx < (oxb - oxa) * 3; idx += 64) {
+                    const int ox = oxa + idx / 3, c = idx % 3;
+                    const int xs = (ox * iw) / S, xe = ((ox + 1) * iw + S - 1) / S;
+                    unsigned acc = 0;
+                    for (int xx = xs; xx < xe; xx++) acc += colbuf[(xx - xsa) * 3 + c];
+                    in_s[(oy * S + ox) * 3 + c] = ((float)acc / kh / (float)(xe - xs) - 127.5f) * 0.0078125f;
+                }
+                __builtin_amdgcn_wave_barrier();
+                oxa = oxb;
+            }
+        }
+        for (int p = IN_N + tid; p < IN_N + 128; p += 256) in_s[p] = 0.f;   // read by the zero-weight k = 27 pad
+    }
+    // ---- conv1 weights: B operands of both 16-channel N-tiles, in registers ----------------------------------
+    float B0[7], B1[7];
+    int koff[7];
+#pragma unroll
+    for (int s = 0; s < 7; s++) {
+        const int k = 4 * s + kq;
+        B0[s] = w1[k * 32 + l15];
+        B1[s] = w1[k * 32 + 16 + l15];
+        koff[s] = k + (S * 3 - 9) * (k / 9);
+    }
+    const float bias0 = b1[l15], bias1 = b1[16 + l15], sl0 = s1[l15], sl1 = s1[16 + l15];
+    __syncthreads();
+
+    float* dst = out + (size_t)blockIdx.x * P * P * C1;
+    for (int p0 = 0; p0 < P; p0 += R) {
+        const int rows0 = 2 * p0;
+        const int nrows = (CW - rows0) < SR ? (CW - rows0) : SR;
+        const int M = nrows * CW;
+        const int ntiles = (M + 15) >> 4;
+        // two M-tiles x two N-tiles = four independent accumulator chains per wave
+        for (int mt = wave; mt < ntiles; mt += 8) {
+            const int mtB = mt + 4;
+            const bool hasB = mtB < ntiles;
+            int mA = mt * 16 + l15; mA = mA < M ? mA : M - 1;
+            int mB = (hasB ? mtB : mt) * 16 + l15; mB = mB < M ? mB : M - 1;
+            const int yA = mA / CW, xA = mA - yA * CW, yB = mB / CW, xB = mB - yB * CW;
+            const int baseA = ((rows0 + yA) * S + xA) * 3, baseB = ((rows0 + yB) * S + xB) * 3;
+            f32x4 a0 = {bias0, bias0, bias0, bias0}, a1 = {bias1, bias1, bias1, bias1}, c0 = a0, c1 = a1;
+#pragma unroll
+            for (int s = 0; s < 7; s++) {
+                const float xa = in_s[baseA + koff[s]];
+                const float xb = in_s[baseB + koff[s]];
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, B0[s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, B1[s], a1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, B0[s], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, B1[s], c1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ra = mt * 16 + kq * 4 + q;
+                if (ra < M) {
+                    const float v0 = a0[q], v1 = a1[q];
+                    c1_s[ra * CLD + l15] = v0 > 0.f ? v0 : sl0 * v0;
+                    if (16 + l15 < C1) c1_s[ra * CLD + 16 + l15] = v1 > 0.f ? v1 : sl1 * v1;
+                }
+                const int rb = mtB * 16 + kq * 4 + q;
+                if (hasB && rb < M) {
+                    const float v0 = c0[q], v1 = c1[q];
+                    c1_s[rb * CLD + l15] = v0 > 0.f ? v0 : sl0 * v0;
+                    if (16 + l15 < C1) c1_s[rb * CLD + 16 + l15] = v1 > 0.f ? v1 : sl1 * v1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MaxPool(3, 2, ceil_mode) of the strip -> global NHWC [P][P][C1] -------------------------------------
+        const int prow = (P - p0) < R ? (P - p0) : R;
+        for (int idx = tid; idx < prow * P * C1; idx += 256) {
+            const int c = idx % C1;
+            const int px = (idx / C1) % P;
+            const int pr = idx / (C1 * P);
+            float best = -INFINITY;
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                const int yy = 2 * pr + dy;
+                if (yy >= nrows) break;
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+                    const int xx = 2 * px + dx;
+                    if (xx >= CW) break;
+                    const float v = c1_s[(yy * CW + xx) * CLD + c];
+                    best = v > best ? v : best;
+                }
+            }
+            dst[((size_t)(p0 + pr) * P + px) * C1 + c] = best;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// R-Net front: pooled [nc][11][11][28]
+int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, int t0, int nc, float* d_pool,
+                          hipStream_t s) {
+    if (nc <= 0) return TRL_OK;
+    const DevW* w = trl_w(c, "rnet.conv1.w");
+    const DevV *b = trl_v(c, "rnet.conv1.b"), *sl = trl_v(c, "rnet.prelu1");
+    if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("rnet.conv1 weights"); return TRL_ERR_WEIGHTS; }
+    k_mtcnn_front<24, 28, 29, 4><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, c->cb.map_local, t0, w->p,
+                                                      b->p, sl->p, d_pool);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+// O-Net front: pooled [nc][23][23][32]
+int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, int t0, int nc, float* d_pool,
+                          hipStream_t s) {
+    if (nc <= 0) return TRL_OK;
+    const DevW* w = trl_w(c, "onet.conv1.w");
+    const DevV *b = trl_v(c, "onet.conv1.b"), *sl = trl_v(c, "onet.prelu1");
+    if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("onet.conv1 weights"); return TRL_ERR_WEIGHTS; }
+    k_mtcnn_front<48, 32, 33, 2><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, c->cb.map_local, t0, w->p,
+                                                     b->p, sl->p, d_pool);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}

@@ -19,13 +19,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 16;
-
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, int WM, int WN, int BK, bool VEC>
 __global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int ASLOTS = BM * 4, APT = (ASLOTS + 255) / 256;
-    constexpr int BSLOTS = BN * 4, BPT = (BSLOTS + 255) / 256;
+    constexpr int KG = BK / 4;                                   // float4 groups along k per chunk
+    constexpr int ASLOTS = BM * KG, APT = (ASLOTS + 255) / 256;
+    constexpr int BSLOTS = BK * (BN / 4), BPT = (BSLOTS + 255) / 256;
     static_assert(WM * WN == 4, "4 waves");
     __shared__ __attribute__((aligned(16))) float As[BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
@@ -49,6 +48,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
 
     float4 areg[APT];
     float4 breg[BPT];
+    const int kpad = (a.K + 15) & ~15;   // rows present in the zero-padded weight matrix
 
     auto load_chunk = [&](int k0) {
 #pragma unroll
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (slot < BSLOTS) {
                 const int kk = slot / (BN / 4), n = n0 + 4 * (slot % (BN / 4));
-                if (n < a.ldw) v = *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + kk) * a.ldw + n);
+                if (n < a.ldw && k0 + kk < kpad) v = *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + kk) * a.ldw + n);
             }
             breg[i] = v;
         }
@@ -179,11 +179,11 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 int launch_cfg(const ConvArgs& a, bool vec, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
-    if (vec) conv_igemm<BM, BN, WM, WN, true><<<grid, 256, 0, s>>>(a);
-    else conv_igemm<BM, BN, WM, WN, false><<<grid, 256, 0, s>>>(a);
+    if (vec) conv_igemm<BM, BN, WM, WN, BK, true><<<grid, 256, 0, s>>>(a);
+    else conv_igemm<BM, BN, WM, WN, 16, false><<<grid, 256, 0, s>>>(a);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
@@ -296,10 +296,13 @@ __global__ __launch_bounds__(64) void drift_kernel(const float* __restrict__ emb
 int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
     if (a.M <= 0) return TRL_OK;
     const bool vec = (a.Cin % 4 == 0) && (a.ldx % 4 == 0) && (a.xoff % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
-    if (a.Cout <= 32) return launch_cfg<128, 32, 4, 1>(a, vec, s);
-    if (a.M >= 16384) return launch_cfg<128, 64, 2, 2>(a, vec, s);
-    if (a.M >= 1024) return launch_cfg<64, 64, 2, 2>(a, vec, s);
-    return launch_cfg<32, 128, 1, 4>(a, vec, s);
+    // Deep K chunks (BK = 64) when K is long: a chunk's MFMAs (BK/2 x 64 cycles per wave tile) must cover
+    // the global-load round trip of the next chunk, the only latency hiding a lone workgroup per CU has.
+    const bool deep = a.K >= 192;
+    if (a.Cout <= 32) return deep ? launch_cfg<128, 32, 4, 1, 64>(a, vec, s) : launch_cfg<128, 32, 4, 1, 16>(a, vec, s);
+    if (a.M >= 16384) return deep ? launch_cfg<128, 64, 2, 2, 32>(a, vec, s) : launch_cfg<128, 64, 2, 2, 16>(a, vec, s);
+    if (a.M >= 1024) return deep ? launch_cfg<64, 64, 2, 2, 64>(a, vec, s) : launch_cfg<64, 64, 2, 2, 16>(a, vec, s);
+    return deep ? launch_cfg<32, 128, 1, 4, 64>(a, vec, s) : launch_cfg<32, 128, 1, 4, 16>(a, vec, s);
 }
 
 int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st, int ceil_mode,

@@ -207,6 +207,37 @@ int trl_run_onet(trl_ctx* c, const float* d_crops, int n, float* d_out16, hipStr
     return R.err;
 }
 
+// R-Net from the fused front end's pooled map [n][11][11][28]
+int trl_run_rnet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out6, hipStream_t s) {
+    if (n <= 0) return TRL_OK;
+    Runner R{c, s};
+    Act x; x.p = const_cast<float*>(d_pool1); x.n = n; x.h = 11; x.w = 11; x.c = 28; x.ld = 28; x.coff = 0;
+    x = R.mconv(x, "rnet", "conv2", "prelu2", 3);
+    x = R.pool(x, 3, 2, 1);
+    x = R.mconv(x, "rnet", "conv3", "prelu3", 2);
+    x = R.mconv(x, "rnet", "dense4", "prelu4", 3);
+    Act out; out.p = d_out6; out.n = n; out.h = 1; out.w = 1; out.c = 6; out.ld = 6; out.coff = 0;
+    R.conv(x, trl_w(c, "rnet.heads.w"), trl_v(c, "rnet.heads.b"), nullptr, nullptr, nullptr, 1, 1, 1, 1, 0, 0,
+           TRL_ACT_NONE, &out, nullptr, 0.f);
+    return R.err;
+}
+// O-Net from the fused front end's pooled map [n][23][23][32]
+int trl_run_onet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out16, hipStream_t s) {
+    if (n <= 0) return TRL_OK;
+    Runner R{c, s};
+    Act x; x.p = const_cast<float*>(d_pool1); x.n = n; x.h = 23; x.w = 23; x.c = 32; x.ld = 32; x.coff = 0;
+    x = R.mconv(x, "onet", "conv2", "prelu2", 3);
+    x = R.pool(x, 3, 2, 1);
+    x = R.mconv(x, "onet", "conv3", "prelu3", 3);
+    x = R.pool(x, 2, 2, 1);
+    x = R.mconv(x, "onet", "conv4", "prelu4", 2);
+    x = R.mconv(x, "onet", "dense5", "prelu5", 3);
+    Act out; out.p = d_out16; out.n = n; out.h = 1; out.w = 1; out.c = 16; out.ld = 16; out.coff = 0;
+    R.conv(x, trl_w(c, "onet.heads.w"), trl_v(c, "onet.heads.b"), nullptr, nullptr, nullptr, 1, 1, 1, 1, 0, 0,
+           TRL_ACT_NONE, &out, nullptr, 0.f);
+    return R.err;
+}
+
 size_t trl_pnet_generic_bytes(int nf, int h, int w) {
     const size_t c1 = (size_t)(h - 2) * (w - 2) * 10, ph = (h - 2 + 1) / 2, pw = (w - 2 + 1) / 2;
     const size_t p1 = ph * pw * 10, c2 = (ph - 2) * (pw - 2) * 16, c3 = (ph - 4) * (pw - 4) * 32;

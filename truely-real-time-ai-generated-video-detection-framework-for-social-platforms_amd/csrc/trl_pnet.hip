@@ -21,6 +21,7 @@
 //                 blockIdx -> tile mapping keeps an XCD on a contiguous run of tiles (halo rows of
 //                 neighbouring tiles hit the same L2).
 #include "trl_ctx.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -55,6 +56,7 @@ struct PnetArgs {
     const float *w1, *w2, *w3, *wh;            // [Kpad][32] zero padded
     const float *b1, *b2, *b3, *bh, *s1, *s2, *s3;
     float thr; int cap;
+    int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); 0 in production
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
 };
 
@@ -143,6 +145,16 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ fra
 // ---- fused PNet --------------------------------------------------------------------------------------
 __device__ __forceinline__ float prelu(float v, float sl) { return v > 0.f ? v : sl * v; }
 
+// A-operand k offsets.  k = 4s+kq walks (tap, channel) of a [pixel][C] LDS tile whose rows are E floats
+// further apart than D consecutive k: offset = k + E*(k/D).  With s a compile-time constant only the step
+// whose four k straddle a multiple of D depends on the lane (kq >= thr), so no per-lane offset tables.
+template <int D, int E>
+__device__ __forceinline__ int koff(int s, int kq, int e1, int e2, int e3) {
+    const int q0 = (4 * s) / D, r0 = (4 * s) % D, thr = D - r0;    // folded after unrolling
+    const int add = thr == 1 ? e1 : (thr == 2 ? e2 : (thr == 3 ? e3 : 0));
+    return 4 * s + E * q0 + kq + add;
+}
+
 __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
@@ -151,14 +163,15 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     const int l15 = lane & 15, kq = lane >> 4;      // 16x16x4 operand coordinates
     const int l31 = lane & 31, hh = lane >> 5;      // 32x32x2 operand coordinates
 
-    // ---- B operands: all weights stay in registers for the whole launch ----------------------------
-    float B1[7], B2[23], B3[72], BH[8];
+    // ---- B operands: every weight matrix stays in registers for the whole launch -----------------------------
+    float B3[72];
+#pragma unroll
+    for (int s = 0; s < 72; s++) B3[s] = a.w3[(2 * s + hh) * 32 + l31];
+    float B1[7], B2[23], BH[8];
 #pragma unroll
     for (int s = 0; s < 7; s++) B1[s] = a.w1[(4 * s + kq) * 32 + l15];
 #pragma unroll
     for (int s = 0; s < 23; s++) B2[s] = a.w2[(4 * s + kq) * 32 + l15];
-#pragma unroll
-    for (int s = 0; s < 72; s++) B3[s] = a.w3[(2 * s + hh) * 32 + l31];
 #pragma unroll
     for (int s = 0; s < 8; s++) BH[s] = a.wh[(4 * s + kq) * 32 + l15];
     const float bias1 = a.b1[l15], slope1 = a.s1[l15];   // vectors are zero padded to 128 floats
@@ -171,16 +184,10 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     for (int i = tid; i < REGION_B; i += 256) RB[i] = 0.f;
     __syncthreads();
 
-    // ---- per-lane A-operand address pieces (floats) ---------------------------------------------------
-    // conv1: row i = pool cell (i>>2) x sub-position (i&3) of a 4-cell group; k = 4s+kq -> k + 117*(k/9)
+    // conv1 rows: i = pool cell (i>>2) x sub-position (i&3) of a 4-cell group
     const int c1_pc = l15 >> 2, c1_dy = (l15 >> 1) & 1, c1_dx = l15 & 1;
-    int koff1[7];
-#pragma unroll
-    for (int s = 0; s < 7; s++) { const int k = 4 * s + kq; koff1[s] = k + 117 * (k / 9); }
-    // conv2: k = 4s+kq -> k + 170*(k/30)
-    int koff2[23];
-#pragma unroll
-    for (int s = 0; s < 23; s++) { const int k = 4 * s + kq; koff2[s] = k + 170 * (k / 30); }
+    const int e1_1 = kq >= 1 ? 117 : 0, e1_2 = kq >= 2 ? 117 : 0, e1_3 = kq >= 3 ? 117 : 0;   // conv1: D = 9,  E = 126-9
+    const int e2_2 = kq >= 2 ? 170 : 0;                                                      // conv2: D = 30, E = 200-30
 
     const int total_tiles = a.tiles_per_frame * a.n_frames;
     // XCD-aware persistent schedule: blocks sharing blockIdx%8 (one XCD) walk one contiguous 1/8 of the tiles
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         const int ty = tq / g.tiles_x, tx = tq - ty * g.tiles_x;
 
         // ---- phase 0: input tile -> RA as [42][42][3] ------------------------------------------------------
-        {
+        if (!(a.dbg_skip & 1)) {
             const float4* src = a.pyr + (long long)f * a.pyr_stride + g.pix0;
             const int gy0 = ty * 2 * TS, gx0 = tx * 2 * TS;
             for (int p = tid; p < IN_T * IN_T; p += 256) {
@@ -212,9 +219,10 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         __syncthreads();
 
         // ---- phase 1: conv1 + PReLU + 2x2 ceil max-pool -> RB as [20][20][10] ------------------------------
-        {
+        if (!(a.dbg_skip & 2)) {
             const int vy = g.h - 2 - ty * 2 * TS, vx = g.w - 2 - tx * 2 * TS;   // valid conv1 extent inside the tile
             // 100 M-tiles (5 groups of 4 pool cells per pooled row); two independent accumulators per wave
+#pragma unroll 1
             for (int j = 0; j < 13; j++) {
                 const int mtA = wave + 8 * j, mtB = mtA + 4;
                 const bool hasB = mtB < 100;
@@ -223,12 +231,18 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 const int baseA = ((2 * pyA + c1_dy) * IN_T + 2 * (4 * pgA + c1_pc) + c1_dx) * 3;
                 const int baseB = ((2 * pyB + c1_dy) * IN_T + 2 * (4 * pgB + c1_pc) + c1_dx) * 3;
                 f32x4 accA = {bias1, bias1, bias1, bias1}, accB = accA;
+                float xa[7], xb[7];     // all A operands of the pair are in flight before the first MFMA
 #pragma unroll
                 for (int s = 0; s < 7; s++) {
-                    const float xa = RA[baseA + koff1[s]];
-                    const float xb = RA[baseB + koff1[s]];
-                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, B1[s], accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, B1[s], accB, 0, 0, 0);
+                    const int ko = koff<9, 117>(s, kq, e1_1, e1_2, e1_3);
+                    xa[s] = RA[baseA + ko];
+                    xb[s] = RA[baseB + ko];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMA chain (counted lgkmcnt waits follow)
+#pragma unroll
+                for (int s = 0; s < 7; s++) {
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B1[s], accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B1[s], accB, 0, 0, 0);
                 }
                 // epilogue: lane holds channel l15 of pool cell kq, the 4 registers are its 2x2 window
                 if (l15 < 10) {
@@ -252,8 +266,10 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         __syncthreads();
 
         // ---- phase 2: conv2 + PReLU -> RA as [324][17] ---------------------------------------------------------
-        {
-            // 21 M-tiles of 16 rows (last one 4 rows); wave w takes w, w+4, ...: pairs (w, w+4), (w+8, w+12), (w+16, w+20)
+        if (!(a.dbg_skip & 4)) {
+            // 21 M-tiles of 16 rows (last one 4 rows); wave w takes pairs (w, w+4), (w+8, w+12), (w+16, w+20).
+            // RA (the input tile) is dead since the barrier above, so the epilogue may overwrite it.
+#pragma unroll 1
             for (int j = 0; j < 3; j++) {
                 const int mtA = wave + 8 * j, mtB = mtA + 4;
                 const bool hasB = mtB < 21;
@@ -262,15 +278,19 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 const int yA = mA / C2_T, xA = mA - yA * C2_T, yB = mB / C2_T, xB = mB - yB * C2_T;
                 const int baseA = (yA * P1_T + xA) * 10, baseB = (yB * P1_T + xB) * 10;
                 f32x4 accA = {bias2, bias2, bias2, bias2}, accB = accA;
+                float xa[23], xb[23];
 #pragma unroll
                 for (int s = 0; s < 23; s++) {
-                    const float xa = RB[baseA + koff2[s]];
-                    const float xb = RB[baseB + koff2[s]];
-                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, B2[s], accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, B2[s], accB, 0, 0, 0);
+                    const int ko = koff<30, 170>(s, kq, 0, e2_2, 0);
+                    xa[s] = RB[baseA + ko];
+                    xb[s] = RB[baseB + ko];
                 }
-                // all conv2 reads of this wave pair are done before RA is written? NO: other waves may still be
-                // reading RB (not RA) -- RA (input tile) is dead since the barrier above, so writes are safe.
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 23; s++) {
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B2[s], accB, 0, 0, 0);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int ra = mtA * 16 + kq * 4 + q;
@@ -283,9 +303,10 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         __syncthreads();
 
         // ---- phase 3: conv3 + PReLU -> per-wave staging -> heads -> candidates -------------------------------
-        {
+        if (!(a.dbg_skip & 8)) {
             float* ST = RB + wave * 32 * ST_LD;
             const float fscale = g.scale;
+#pragma unroll 1
             for (int it = 0; it < 2; it++) {
                 const int mt = wave + 4 * it;               // 8 M-tiles of 32 rows = 2 output rows each
                 const int y = mt * 2 + (l31 >> 4), x = l31 & 15;
@@ -294,10 +315,16 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[q] = bias3;
 #pragma unroll
-                for (int s = 0; s < 72; s++) {
-                    const int tap = s >> 3, ky = tap / 3, kx = tap - ky * 3;
-                    const float xa = RA[base + (ky * C2_T + kx) * C2_LD + 2 * (s & 7)];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, B3[s], acc, 0, 0, 0);
+                for (int half = 0; half < 3; half++) {      // 3 x 24 k-steps: the operands of a third are all in flight first
+                    float xa[24];
+#pragma unroll
+                    for (int u = 0; u < 24; u++) {
+                        const int s = half * 24 + u, tap = s >> 3, ky = tap / 3, kx = tap - ky * 3;
+                        xa[u] = RA[base + (ky * C2_T + kx) * C2_LD + 2 * (s & 7)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 24; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u], B3[half * 24 + u], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
@@ -411,6 +438,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
     a.b1 = trl_v(c, "pnet.conv1.b")->p; a.b2 = trl_v(c, "pnet.conv2.b")->p; a.b3 = trl_v(c, "pnet.conv3.b")->p; a.bh = trl_v(c, "pnet.heads.b")->p;
     a.s1 = trl_v(c, "pnet.prelu1")->p; a.s2 = trl_v(c, "pnet.prelu2")->p; a.s3 = trl_v(c, "pnet.prelu3")->p;
     a.thr = c->cfg.thr0; a.cap = c->cfg.cap_level;
+    { const char* e = getenv("TRL_PNET_SKIP"); a.dbg_skip = e ? atoi(e) : 0; }
     a.lvl_cnt = c->cb.lvl_cnt; a.lvl_rec = c->cb.lvl_rec; a.flags = c->cb.flags;
     return TRL_OK;
 }
@@ -448,7 +476,7 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     TRL_LAUNCH_CHECK();
     if (ev) { TRL_HIP(hipEventRecord(ev[1], s)); TRL_HIP(hipEventRecord(ev[2], s)); }
     const int total_tiles = a.tiles_per_frame * n;
-    int grid = 256 * 2;                       // 2 resident workgroups per CU (LDS 38 KB, <= 256 VGPRs)
+    int grid = 256 * 2;                       // 2 resident workgroups per CU (<= 256 VGPRs)
     if (grid > ((total_tiles + 7) / 8) * 8) grid = ((total_tiles + 7) / 8) * 8;
     if (grid < 8) grid = 8;
     k_pnet_fused<<<grid, 256, 0, s>>>(a);
