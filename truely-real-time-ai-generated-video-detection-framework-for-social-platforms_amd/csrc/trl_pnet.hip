@@ -25,6 +25,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at dword alignment
+struct __attribute__((packed, aligned(4))) u32x3_a4 { unsigned x, y, z; };
 
 namespace {
 
@@ -46,6 +48,8 @@ struct PLevel {
     int pix_pad;             // h*w rounded up to 64 (pyramid slots of the level)
     int gshift, work0;       // pyramid kernel: log2(lanes per pixel), first thread of the level inside a frame
     int ytab0, xtab0;        // offsets of the level's row / column bin-edge tables
+    int mode, nd, grshift;   // pyramid kernel path, re-aligned dwords per row (mode 0), log2 groups per row (mode 1)
+    unsigned wmagic;         // ceil(2^32 / w): pixel / w by __umulhi
     float scale;
 };
 struct PnetArgs {
@@ -83,35 +87,129 @@ __device__ __forceinline__ void dword_sums(unsigned v, int rel, int nbytes, unsi
 
 // Bin edges are precomputed on the host (one packed (start | end<<16) word per output row / column of
 // every level): the kernel does no 64-bit or repeated integer division.  grid = (blocks, frames).
-__global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ frames, PnetArgs a, const uint32_t* __restrict__ tab,
+// Three per-level modes (wave-uniform):
+//   0  small bins (<= 5 px wide): one lane per pixel; each source row is 4-5 aligned dwords re-aligned to
+//      the bin's first byte with v_alignbyte, so the BGR byte->channel masks are compile-time constants;
+//   1  big bins, row pitch a multiple of 4 bytes: a lane owns one 12-byte group (4 whole pixels, constant
+//      channel phase) of the bin for every (rl-th) source row: 3 coalesced loads + 9 v_dot4 per 12 bytes;
+//   2  generic fallback (odd row pitch): flattened (row, dword) walk with per-dword masks.
+__device__ __forceinline__ unsigned chan_mask(int p, int c) {   // dword whose byte 0 has channel p: bytes of channel c
+    const int d = (c - p + 3) % 3;                               // byte index of the first byte of channel c
+    return d == 0 ? 0x01000001u : (d == 1 ? 0x00000100u : 0x00010000u);
+}
+__device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF for bytes b of the dword with 0 <= rel+b < nbytes
+    const int lo = rel < 0 ? -rel : 0;
+    int hi = nbytes - rel; hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+    if (lo >= hi) return 0u;
+    return (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+}
+
+struct PyrArgs { int H, W, n_frames; long long pyr_stride; PLevel g; };
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ frames, PyrArgs a, const uint32_t* __restrict__ tab,
                                                  float4* __restrict__ pyr) {
-    const int per_frame = (int)a.work_per_frame;           // threads per frame, multiple of 64
+    const PLevel& g = a.g;                                  // one launch per level: every field is a kernel argument (SGPRs)
+    const int per_frame = g.pix_pad << g.gshift;            // threads of this level per frame
+    constexpr int mode = MODE;
     const int f = blockIdx.y;
     const uint32_t* base32 = reinterpret_cast<const uint32_t*>(frames);
     const long long fbase = (long long)f * a.H * a.W * 3;
+    const long long last_dw = ((long long)a.n_frames * a.H * a.W * 3 - 1) >> 2;
     const int row_bytes = a.W * 3;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < per_frame; p += gridDim.x * blockDim.x) {
-        int l = 0;
-        while (l + 1 < a.L && p >= a.lv[l + 1].work0) l++;   // wave-uniform: level boundaries are multiples of 64
-        const PLevel& g = a.lv[l];
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < per_frame; q += gridDim.x * blockDim.x) {
         const int w = g.w, gsh = g.gshift, G = 1 << gsh;
-        const int q = p - g.work0;
         const int pixel = q >> gsh, sub = q & (G - 1);
         const bool valid = pixel < g.h * w;
         unsigned s0 = 0, s1 = 0, s2 = 0;
         int kh = 1, kw = 1;
         if (valid) {
-            const int oy = pixel / w, ox = pixel - oy * w;
+            const int oy = (int)__umulhi((unsigned)pixel, g.wmagic), ox = pixel - oy * w;
             const uint32_t ty = tab[g.ytab0 + oy], tx = tab[g.xtab0 + ox];
             const int ys = ty & 0xFFFF, ye = ty >> 16, xs = tx & 0xFFFF, xe = tx >> 16;
             kh = ye - ys; kw = xe - xs;
             const int nbytes = kw * 3;
             const long long o0 = fbase + (long long)ys * row_bytes + xs * 3;   // first byte of the bin
-            if (G == 1) {
-                long long o = o0;
-                for (int y = 0; y < kh; y++, o += row_bytes) {
-                    long long al = o & ~3ll;
-                    for (int rel = (int)(al - o); rel < nbytes; rel += 4, al += 4) dword_sums(base32[al >> 2], rel, nbytes, s0, s1, s2);
+            if (mode == 0) {
+                const unsigned vm0 = valid_bytes(0, nbytes), vm1 = valid_bytes(4, nbytes), vm2 = valid_bytes(8, nbytes),
+                               vm3 = valid_bytes(12, nbytes);
+                const bool four = g.nd > 3;
+                // rows in batches of 4: all loads of a batch are in flight before any is consumed (one latency, not kh)
+                for (int y0 = 0; y0 < kh; y0 += 4) {
+                    unsigned ww[4][5];
+                    unsigned shv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int y = (y0 + r < kh) ? y0 + r : kh - 1;
+                        const long long o = o0 + (long long)y * row_bytes;
+                        const long long dw = o >> 2;
+                        shv[r] = (unsigned)(o & 3);
+                        if (dw + 4 <= last_dw) {   // dword-aligned 16-byte load (+1 dword when bins reach 5 px)
+                            const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(base32 + dw);
+                            ww[r][0] = v4[0]; ww[r][1] = v4[1]; ww[r][2] = v4[2]; ww[r][3] = v4[3];
+                            ww[r][4] = four ? base32[dw + 4] : 0u;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 5; j++) ww[r][j] = base32[dw + j <= last_dw ? dw + j : last_dw];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const bool act = y0 + r < kh;
+                        const unsigned sh = shv[r];
+                        const unsigned d0 = __builtin_amdgcn_alignbyte(ww[r][1], ww[r][0], sh) & (act ? vm0 : 0u);
+                        const unsigned d1 = __builtin_amdgcn_alignbyte(ww[r][2], ww[r][1], sh) & (act ? vm1 : 0u);
+                        const unsigned d2 = __builtin_amdgcn_alignbyte(ww[r][3], ww[r][2], sh) & (act ? vm2 : 0u);
+                        const unsigned d3 = __builtin_amdgcn_alignbyte(ww[r][4], ww[r][3], sh) & ((act && four) ? vm3 : 0u);
+                        s0 = __builtin_amdgcn_udot4(d0, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d0, 0x00000100u, s1, false);
+                        s2 = __builtin_amdgcn_udot4(d0, 0x00010000u, s2, false);
+                        s0 = __builtin_amdgcn_udot4(d1, 0x00010000u, s0, false); s1 = __builtin_amdgcn_udot4(d1, 0x01000001u, s1, false);
+                        s2 = __builtin_amdgcn_udot4(d1, 0x00000100u, s2, false);
+                        s0 = __builtin_amdgcn_udot4(d2, 0x00000100u, s0, false); s1 = __builtin_amdgcn_udot4(d2, 0x00010000u, s1, false);
+                        s2 = __builtin_amdgcn_udot4(d2, 0x01000001u, s2, false);
+                        s0 = __builtin_amdgcn_udot4(d3, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d3, 0x00000100u, s1, false);
+                        s2 = __builtin_amdgcn_udot4(d3, 0x00010000u, s2, false);
+                    }
+                }
+            } else if (mode == 1) {
+                const int grsh = g.grshift, grp = sub & ((1 << grsh) - 1), rlane = sub >> grsh, rl = G >> grsh;
+                const int sh = (int)(o0 & 3);
+                const int rel = -sh + 12 * grp;                      // offset of this lane's group relative to the bin's first byte
+                if (rel < nbytes) {
+                    const int ph = (3 - sh % 3) % 3;                 // channel of the byte at the aligned start (12*grp keeps it)
+                    unsigned mk[3][3];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const unsigned vb = valid_bytes(rel + 4 * j, nbytes) & 0x01010101u;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) mk[j][c] = chan_mask((ph + j) % 3, c) & vb;
+                    }
+                    long long dw = ((o0 - sh) >> 2) + 3 * grp + (long long)rlane * (row_bytes >> 2);
+                    const long long dstep = (long long)rl * (row_bytes >> 2);
+                    for (int y = rlane; y < kh; y += 4 * rl, dw += 4 * dstep) {
+                        unsigned w3[4][3];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const bool act = y + r * rl < kh;
+                            const long long d = act ? dw + r * dstep : dw;
+                            if (d + 2 <= last_dw) {
+                                const u32x3_a4 v3 = *reinterpret_cast<const u32x3_a4*>(base32 + d);
+                                w3[r][0] = v3.x; w3[r][1] = v3.y; w3[r][2] = v3.z;
+                            } else {
+                                w3[r][0] = base32[d]; w3[r][1] = base32[d + 1 <= last_dw ? d + 1 : last_dw]; w3[r][2] = base32[last_dw];
+                            }
+                            if (!act) { w3[r][0] = 0u; w3[r][1] = 0u; w3[r][2] = 0u; }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            s0 = __builtin_amdgcn_udot4(w3[r][0], mk[0][0], s0, false); s1 = __builtin_amdgcn_udot4(w3[r][0], mk[0][1], s1, false);
+                            s2 = __builtin_amdgcn_udot4(w3[r][0], mk[0][2], s2, false);
+                            s0 = __builtin_amdgcn_udot4(w3[r][1], mk[1][0], s0, false); s1 = __builtin_amdgcn_udot4(w3[r][1], mk[1][1], s1, false);
+                            s2 = __builtin_amdgcn_udot4(w3[r][1], mk[1][2], s2, false);
+                            s0 = __builtin_amdgcn_udot4(w3[r][2], mk[2][0], s0, false); s1 = __builtin_amdgcn_udot4(w3[r][2], mk[2][1], s1, false);
+                            s2 = __builtin_amdgcn_udot4(w3[r][2], mk[2][2], s2, false);
+                        }
+                    }
                 }
             } else {
                 const int ndw = (nbytes + 6) >> 2;            // dwords per row for the worst alignment
@@ -158,6 +256,7 @@ __device__ __forceinline__ int koff(int s, int kq, int e1, int e2, int e3) {
 __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
+    __shared__ float HSall[4 * 32 * 9];                           // per-wave head outputs [32 cells][9]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;      // 16x16x4 operand coordinates
@@ -195,72 +294,109 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     const int chunk = (total_tiles + 7) / 8;
     const int t_begin = xcd * chunk, t_end = (t_begin + chunk < total_tiles) ? t_begin + chunk : total_tiles;
 
-    for (int tile = t_begin + slot; tile < t_end; tile += per_xcd_blocks) {
-        const int f = tile / a.tiles_per_frame;
+    // tile -> (frame, level, ty, tx)
+    auto decode = [&](int tile, int& f, int& l, int& ty, int& tx) {
+        f = tile / a.tiles_per_frame;
         const int tt = tile - f * a.tiles_per_frame;
-        int l = 0;
+        l = 0;
         while (l + 1 < a.L && tt >= a.lv[l + 1].tile0) l++;
+        const int tq = tt - a.lv[l].tile0;
+        ty = tq / a.lv[l].tiles_x;
+        tx = tq - ty * a.lv[l].tiles_x;
+    };
+    // The next tile's 42x42 input pixels are fetched into registers while the current tile is in phase 3
+    // (7 float4 per thread) and dropped into LDS at the top of the next iteration: the HBM/L2 latency of the
+    // only global read of the kernel is off the critical path.
+    float4 pre[7];
+    auto issue_input = [&](int tile) {
+        int f, l, ty, tx;
+        decode(tile, f, l, ty, tx);
         const PLevel& g = a.lv[l];
-        const int tq = tt - g.tile0;
-        const int ty = tq / g.tiles_x, tx = tq - ty * g.tiles_x;
+        const float4* src = a.pyr + (long long)f * a.pyr_stride + g.pix0;
+        const int gy0 = ty * 2 * TS, gx0 = tx * 2 * TS;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int p = tid + 256 * i;
+            const int iy = p / IN_T, ix = p - iy * IN_T;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            pre[i] = (p < IN_T * IN_T && gy < g.h && gx < g.w) ? src[(long long)gy * g.w + gx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
 
-        // ---- phase 0: input tile -> RA as [42][42][3] ------------------------------------------------------
-        if (!(a.dbg_skip & 1)) {
-            const float4* src = a.pyr + (long long)f * a.pyr_stride + g.pix0;
-            const int gy0 = ty * 2 * TS, gx0 = tx * 2 * TS;
-            for (int p = tid; p < IN_T * IN_T; p += 256) {
-                const int iy = p / IN_T, ix = p - iy * IN_T;
-                const int gy = gy0 + iy, gx = gx0 + ix;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy < g.h && gx < g.w) v = src[(long long)gy * g.w + gx];
-                RA[3 * p + 0] = v.x; RA[3 * p + 1] = v.y; RA[3 * p + 2] = v.z;
-            }
+    float* const HS = HSall + wave * 32 * 9;
+    int tile = t_begin + slot;
+    if (tile < t_end) issue_input(tile);
+    for (; tile < t_end; tile += per_xcd_blocks) {
+        int f, l, ty, tx;
+        decode(tile, f, l, ty, tx);
+        const PLevel& g = a.lv[l];
+
+        // ---- phase 0: prefetched input tile -> RA as [42][42][3] ---------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int p = tid + 256 * i;
+            if (p < IN_T * IN_T) { RA[3 * p + 0] = pre[i].x; RA[3 * p + 1] = pre[i].y; RA[3 * p + 2] = pre[i].z; }
         }
         __syncthreads();
 
         // ---- phase 1: conv1 + PReLU + 2x2 ceil max-pool -> RB as [20][20][10] ------------------------------
+        // 100 M-tiles (5 groups of 4 pool cells per pooled row), 25 per wave, processed as pairs of independent
+        // accumulator chains.  Software pipeline: the A operands of pair j+1 are read from LDS before the MFMAs of
+        // pair j are issued, and the (branch-free) pool epilogue of pair j runs in the shadow of those MFMAs.
         if (!(a.dbg_skip & 2)) {
             const int vy = g.h - 2 - ty * 2 * TS, vx = g.w - 2 - tx * 2 * TS;   // valid conv1 extent inside the tile
-            // 100 M-tiles (5 groups of 4 pool cells per pooled row); two independent accumulators per wave
-#pragma unroll 1
-            for (int j = 0; j < 13; j++) {
-                const int mtA = wave + 8 * j, mtB = mtA + 4;
-                const bool hasB = mtB < 100;
-                const int pyA = mtA / 5, pgA = mtA - pyA * 5;
-                const int pyB = hasB ? mtB / 5 : pyA, pgB = hasB ? mtB - (mtB / 5) * 5 : pgA;
-                const int baseA = ((2 * pyA + c1_dy) * IN_T + 2 * (4 * pgA + c1_pc) + c1_dx) * 3;
-                const int baseB = ((2 * pyB + c1_dy) * IN_T + 2 * (4 * pgB + c1_pc) + c1_dx) * 3;
-                f32x4 accA = {bias1, bias1, bias1, bias1}, accB = accA;
-                float xa[7], xb[7];     // all A operands of the pair are in flight before the first MFMA
+            float xs0[14], xs1[14];
+            auto tile_base = [&](int mt) {
+                const int py = mt / 5, pg = mt - py * 5;
+                return ((2 * py + c1_dy) * IN_T + 2 * (4 * pg + c1_pc) + c1_dx) * 3;
+            };
+            auto read_pair = [&](int j, float (&x)[14]) {
+                const int mtA = wave + 8 * j, mtB = (mtA + 4 < 100) ? mtA + 4 : mtA;
+                const int baseA = tile_base(mtA), baseB = tile_base(mtB);
 #pragma unroll
                 for (int s = 0; s < 7; s++) {
                     const int ko = koff<9, 117>(s, kq, e1_1, e1_2, e1_3);
-                    xa[s] = RA[baseA + ko];
-                    xb[s] = RA[baseB + ko];
+                    x[s] = RA[baseA + ko];
+                    x[7 + s] = RA[baseB + ko];
                 }
-                __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMA chain (counted lgkmcnt waits follow)
+            };
+            auto pool_store = [&](const f32x4& acc, int mt) {
+                const int py = mt / 5, px = 4 * (mt - py * 5) + kq;
+                const bool r0 = 2 * py < vy, r1 = 2 * py + 1 < vy, c0 = 2 * px < vx, c1 = 2 * px + 1 < vx;
+                const float v0 = prelu(acc[0], slope1), v1 = prelu(acc[1], slope1), v2 = prelu(acc[2], slope1), v3 = prelu(acc[3], slope1);
+                float m = v0;                                     // (dy,dx) = (0,0) is valid whenever the cell is
+                m = (r0 && c1 && v1 > m) ? v1 : m;
+                m = (r1 && c0 && v2 > m) ? v2 : m;
+                m = (r1 && c1 && v3 > m) ? v3 : m;
+                if (l15 < 10) RB[(py * P1_T + px) * 10 + l15] = (r0 && c0) ? m : 0.f;
+            };
+            auto mma_pair = [&](const float (&x)[14], f32x4& accA, f32x4& accB) {
+                accA = f32x4{bias1, bias1, bias1, bias1};
+                accB = accA;
 #pragma unroll
                 for (int s = 0; s < 7; s++) {
-                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B1[s], accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B1[s], accB, 0, 0, 0);
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], B1[s], accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(x[7 + s], B1[s], accB, 0, 0, 0);
                 }
-                // epilogue: lane holds channel l15 of pool cell kq, the 4 registers are its 2x2 window
-                if (l15 < 10) {
-#pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        if (t == 1 && !hasB) break;
-                        const f32x4 acc = t ? accB : accA;
-                        const int py = t ? pyB : pyA, px = 4 * (t ? pgB : pgA) + kq;
-                        float m = -INFINITY;
-                        bool any = false;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int y = 2 * py + (q >> 1), x = 2 * px + (q & 1);
-                            if (y < vy && x < vx) { const float v = prelu(acc[q], slope1); m = v > m ? v : m; any = true; }
-                        }
-                        RB[(py * P1_T + px) * 10 + l15] = any ? m : 0.f;
-                    }
-                }
+            };
+            read_pair(0, xs0);
+#pragma unroll 1
+            for (int jj = 0; jj < 6; jj++) {
+                f32x4 aA, aB, bA, bB;
+                read_pair(2 * jj + 1, xs1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_pair(xs0, aA, aB);
+                read_pair(2 * jj + 2, xs0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_pair(xs1, bA, bB);
+                const int mt0 = wave + 16 * jj;
+                pool_store(aA, mt0); pool_store(aB, mt0 + 4);
+                pool_store(bA, mt0 + 8); pool_store(bB, mt0 + 12);
+            }
+            {   // pair 12: M-tile wave+96 only (wave+100 does not exist)
+                f32x4 aA, aB;
+                mma_pair(xs0, aA, aB);
+                pool_store(aA, wave + 96);
             }
         }
         __syncthreads();
@@ -302,6 +438,9 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         }
         __syncthreads();
 
+        // next tile's input: global loads into registers only (RA is still read by phase 3)
+        if (tile + per_xcd_blocks < t_end) issue_input(tile + per_xcd_blocks);
+
         // ---- phase 3: conv3 + PReLU -> per-wave staging -> heads -> candidates -------------------------------
         if (!(a.dbg_skip & 8)) {
             float* ST = RB + wave * 32 * ST_LD;
@@ -341,40 +480,35 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     hA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, BH[s], hA, 0, 0, 0);
                     hB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, BH[s], hB, 0, 0, 0);
                 }
-                __builtin_amdgcn_wave_barrier();
-                // lane (n = l15, rows kq*4+q): n=0,1 class logits, n=2..5 box regression
-                const int lbase = lane & ~15;
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const f32x4 hv = t ? hB : hA;
+                // lane (n = l15, rows kq*4+q): n=0,1 class logits, n=2..5 box regression -> [row][9] staging
+                if (l15 < 6) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const float v = hv[q];
-                        const float l0 = __shfl(v, lbase + 0, 64);
-                        const float r0 = __shfl(v, lbase + 2, 64), r1 = __shfl(v, lbase + 3, 64);
-                        const float r2 = __shfl(v, lbase + 4, 64), r3 = __shfl(v, lbase + 5, 64);
-                        if (l15 == 1) {
-                            const int row = t * 16 + kq * 4 + q;            // row inside the 32-row tile
-                            const int oy = ty * TS + mt * 2 + (row >> 4), ox = tx * TS + (row & 15);
-                            if (oy < g.oh && ox < g.ow) {
-                                const float p = trl_softmax2_p1(l0, v);
-                                if (p >= a.thr) {
-                                    const int seg = f * a.L + l;
-                                    const int sl = atomicAdd(&a.lvl_cnt[seg], 1);
-                                    if (sl < a.cap) {
-                                        Cand c;
-                                        c.x1 = floorf((2.f * (float)ox + 1.f) / fscale);
-                                        c.y1 = floorf((2.f * (float)oy + 1.f) / fscale);
-                                        c.x2 = floorf((2.f * (float)ox + 12.f) / fscale);
-                                        c.y2 = floorf((2.f * (float)oy + 12.f) / fscale);
-                                        c.score = p;
-                                        c.r0 = r0; c.r1 = r1; c.r2 = r2; c.r3 = r3;
-                                        c.cell = oy * g.ow + ox;
-                                        a.lvl_rec[(size_t)seg * a.cap + sl] = c;
-                                    } else {
-                                        a.flags[0] = 1;
-                                    }
-                                }
+                        HS[(kq * 4 + q) * 9 + l15] = hA[q];
+                        HS[(16 + kq * 4 + q) * 9 + l15] = hB[q];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32) {                            // one lane per cell of the 32-row tile
+                    const int oy = ty * TS + mt * 2 + (lane >> 4), ox = tx * TS + (lane & 15);
+                    if (oy < g.oh && ox < g.ow) {
+                        const float* hv = HS + lane * 9;
+                        const float p = trl_softmax2_p1(hv[0], hv[1]);
+                        if (p >= a.thr) {
+                            const int seg = f * a.L + l;
+                            const int sl = atomicAdd(&a.lvl_cnt[seg], 1);
+                            if (sl < a.cap) {
+                                Cand c;
+                                c.x1 = floorf((2.f * (float)ox + 1.f) / fscale);
+                                c.y1 = floorf((2.f * (float)oy + 1.f) / fscale);
+                                c.x2 = floorf((2.f * (float)ox + 12.f) / fscale);
+                                c.y2 = floorf((2.f * (float)oy + 12.f) / fscale);
+                                c.score = p;
+                                c.r0 = hv[2]; c.r1 = hv[3]; c.r2 = hv[4]; c.r3 = hv[5];
+                                c.cell = oy * g.ow + ox;
+                                a.lvl_rec[(size_t)seg * a.cap + sl] = c;
+                            } else {
+                                a.flags[0] = 1;
                             }
                         }
                     }
@@ -416,10 +550,25 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
         p.pix0 = (int)pix;
         p.pix_pad = (int)(((long long)g.h * g.w + 63) & ~63ll);
         pix += p.pix_pad;
-        // lanes per output pixel: keep a lane's share of the bin near <= 32 dwords
-        const int kh = (H + g.h - 1) / g.h + 1, ndw = (((W + g.w - 1) / g.w + 1) * 3 + 6) / 4;
-        const int dwords = kh * ndw;
-        p.gshift = dwords <= 40 ? 0 : (dwords <= 160 ? 2 : (dwords <= 640 ? 4 : 6));
+        // pyramid kernel path and lanes per output pixel
+        const int khmax = (H + g.h - 1) / g.h + 1, kwmax = (W + g.w - 1) / g.w + 1;
+        p.wmagic = (unsigned)((0x100000000ull + g.w - 1) / g.w);
+        p.nd = 3; p.grshift = 0;
+        if (kwmax * 3 <= 15) {
+            p.mode = 0; p.gshift = 0; p.nd = kwmax * 3 <= 9 ? 3 : 4;
+        } else if ((W * 3) % 4 == 0) {
+            p.mode = 1;
+            const int ngr = (kwmax * 3 + 3 + 11) / 12;
+            while ((1 << p.grshift) < ngr) p.grshift++;
+            int rlsh = 0;
+            while ((khmax >> rlsh) > 8 && p.grshift + rlsh < 6) rlsh++;
+            p.gshift = p.grshift + rlsh;
+            if (p.gshift > 6) { p.mode = 2; p.gshift = 6; }
+        } else {
+            p.mode = 2;
+            const int dwords = khmax * ((kwmax * 3 + 6) / 4);
+            p.gshift = dwords <= 40 ? 0 : (dwords <= 160 ? 2 : (dwords <= 640 ? 4 : 6));
+        }
         p.work0 = (int)work;
         work += (long long)p.pix_pad << p.gshift;
         // adaptive_avg_pool2d bin edges: [floor(i*in/out), ceil((i+1)*in/out))
@@ -469,11 +618,17 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     float4* pyr = (float4*)c->scratch.alloc((size_t)a.pyr_stride * n * sizeof(float4));
     if (!pyr) { trl_set_error("pyramid workspace"); return TRL_ERR_STATE; }
     a.pyr = pyr;
-    int blocks = (int)((a.work_per_frame + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
     if (ev) TRL_HIP(hipEventRecord(ev[0], s));
-    k_pyramid<<<dim3(blocks, n), 256, 0, s>>>(d_frames, a, c->pyr_tab, pyr);
-    TRL_LAUNCH_CHECK();
+    for (int l = 0; l < a.L; l++) {
+        PyrArgs pa;
+        pa.H = H; pa.W = W; pa.n_frames = n; pa.pyr_stride = a.pyr_stride; pa.g = a.lv[l];
+        const int threads = pa.g.pix_pad << pa.g.gshift;
+        dim3 grid((threads + 255) / 256, n);
+        if (pa.g.mode == 0) k_pyramid<0><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+        else if (pa.g.mode == 1) k_pyramid<1><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+        else k_pyramid<2><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+        TRL_LAUNCH_CHECK();
+    }
     if (ev) { TRL_HIP(hipEventRecord(ev[1], s)); TRL_HIP(hipEventRecord(ev[2], s)); }
     const int total_tiles = a.tiles_per_frame * n;
     int grid = 256 * 2;                       // 2 resident workgroups per CU (<= 256 VGPRs)
