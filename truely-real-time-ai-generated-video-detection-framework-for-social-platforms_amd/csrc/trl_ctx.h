@@ -46,6 +46,7 @@ struct trl_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pnet_ev;
     int pnet_ev_used = 0;
     float last_ms[4] = {0, 0, 0, 0};
+    int pnet_mono1 = 0;              // conv1 PReLU slopes all >= 0
     uint32_t* pyr_tab = nullptr;     // pyramid bin-edge tables for the last (H, W)
     int pyr_tab_H = 0, pyr_tab_W = 0;
 };

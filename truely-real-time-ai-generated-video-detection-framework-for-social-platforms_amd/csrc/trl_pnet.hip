@@ -61,6 +61,7 @@ struct PnetArgs {
     const float *b1, *b2, *b3, *bh, *s1, *s2, *s3;
     float thr; int cap;
     int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); 0 in production
+    int mono1;                                 // all conv1 PReLU slopes >= 0 (pool/PReLU may be swapped)
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
 };
 
@@ -294,12 +295,17 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     const int chunk = (total_tiles + 7) / 8;
     const int t_begin = xcd * chunk, t_end = (t_begin + chunk < total_tiles) ? t_begin + chunk : total_tiles;
 
-    // tile -> (frame, level, ty, tx)
+    // tile -> (frame, level, ty, tx).  The per-level first-tile table is read once (it stays in scalar
+    // registers); the level is a branch-free count, not a dependent chain of kernarg loads per tile.
+    int lvl_t0[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) lvl_t0[i] = i < a.L ? a.lv[i].tile0 : 0x7fffffff;
     auto decode = [&](int tile, int& f, int& l, int& ty, int& tx) {
         f = tile / a.tiles_per_frame;
         const int tt = tile - f * a.tiles_per_frame;
         l = 0;
-        while (l + 1 < a.L && tt >= a.lv[l + 1].tile0) l++;
+#pragma unroll
+        for (int i = 1; i < 16; i++) l += (tt >= lvl_t0[i]) ? 1 : 0;
         const int tq = tt - a.lv[l].tile0;
         ty = tq / a.lv[l].tiles_x;
         tx = tq - ty * a.lv[l].tiles_x;
@@ -360,15 +366,25 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     x[7 + s] = RA[baseB + ko];
                 }
             };
+            // max-pool commutes with PReLU when the slope is >= 0 (monotone): pool first, one PReLU per cell.
+            // Interior tiles (every conv1 pixel of the tile inside the level) also skip the ceil-mode masks.
+            const bool fast = a.mono1 && vy >= 2 * P1_T && vx >= 2 * P1_T;
             auto pool_store = [&](const f32x4& acc, int mt) {
                 const int py = mt / 5, px = 4 * (mt - py * 5) + kq;
-                const bool r0 = 2 * py < vy, r1 = 2 * py + 1 < vy, c0 = 2 * px < vx, c1 = 2 * px + 1 < vx;
-                const float v0 = prelu(acc[0], slope1), v1 = prelu(acc[1], slope1), v2 = prelu(acc[2], slope1), v3 = prelu(acc[3], slope1);
-                float m = v0;                                     // (dy,dx) = (0,0) is valid whenever the cell is
-                m = (r0 && c1 && v1 > m) ? v1 : m;
-                m = (r1 && c0 && v2 > m) ? v2 : m;
-                m = (r1 && c1 && v3 > m) ? v3 : m;
-                if (l15 < 10) RB[(py * P1_T + px) * 10 + l15] = (r0 && c0) ? m : 0.f;
+                float outv;
+                if (fast) {
+                    const float m01 = acc[0] > acc[1] ? acc[0] : acc[1], m23 = acc[2] > acc[3] ? acc[2] : acc[3];
+                    outv = prelu(m01 > m23 ? m01 : m23, slope1);
+                } else {
+                    const bool r0 = 2 * py < vy, r1 = 2 * py + 1 < vy, c0 = 2 * px < vx, c1 = 2 * px + 1 < vx;
+                    const float v0 = prelu(acc[0], slope1), v1 = prelu(acc[1], slope1), v2 = prelu(acc[2], slope1), v3 = prelu(acc[3], slope1);
+                    float m = v0;                                     // (dy,dx) = (0,0) is valid whenever the cell is
+                    m = (r0 && c1 && v1 > m) ? v1 : m;
+                    m = (r1 && c0 && v2 > m) ? v2 : m;
+                    m = (r1 && c1 && v3 > m) ? v3 : m;
+                    outv = (r0 && c0) ? m : 0.f;
+                }
+                if (l15 < 10) RB[(py * P1_T + px) * 10 + l15] = outv;
             };
             auto mma_pair = [&](const float (&x)[14], f32x4& accA, f32x4& accB) {
                 accA = f32x4{bias1, bias1, bias1, bias1};
@@ -532,6 +548,10 @@ int trl_pnet_prepare(trl_ctx* c) {
         trl_set_error("PNet weights have unexpected shapes");
         return TRL_ERR_WEIGHTS;
     }
+    float sl[10];
+    TRL_HIP(hipMemcpy(sl, trl_v(c, "pnet.prelu1")->p, sizeof sl, hipMemcpyDeviceToHost));
+    c->pnet_mono1 = 1;
+    for (float v : sl) if (!(v >= 0.f)) c->pnet_mono1 = 0;
     return TRL_OK;
 }
 
@@ -588,6 +608,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
     a.s1 = trl_v(c, "pnet.prelu1")->p; a.s2 = trl_v(c, "pnet.prelu2")->p; a.s3 = trl_v(c, "pnet.prelu3")->p;
     a.thr = c->cfg.thr0; a.cap = c->cfg.cap_level;
     { const char* e = getenv("TRL_PNET_SKIP"); a.dbg_skip = e ? atoi(e) : 0; }
+    a.mono1 = c->pnet_mono1;
     a.lvl_cnt = c->cb.lvl_cnt; a.lvl_rec = c->cb.lvl_rec; a.flags = c->cb.flags;
     return TRL_OK;
 }
