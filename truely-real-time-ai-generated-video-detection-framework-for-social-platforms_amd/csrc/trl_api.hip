@@ -172,7 +172,53 @@ extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
         add_vec(net + ".heads.b", tot, bias.data());
         return TRL_OK;
     };
-    keep_alive.reserve(16);
+    keep_alive.reserve(512);
+    // FaceNet: 1x1 BasicConv2d branches that read the same input run as ONE conv with concatenated output
+    // columns (each column keeps its own fmaf chain, so results are unchanged): fewer, wider launches.
+    auto fuse_bconv = [&](const std::string& out, const std::vector<std::string>& parts) -> int {
+        int K = -1, tot = 0;
+        for (auto& p : parts) {
+            auto it = idx.find(p + ".w");
+            if (it == idx.end() || idx.find(p + ".scale") == idx.end() || idx.find(p + ".shift") == idx.end()) {
+                trl_set_error("missing tensors of %s", p.c_str());
+                return TRL_ERR_WEIGHTS;
+            }
+            if (K < 0) K = (int)it->second->dims[0];
+            if (K != (int)it->second->dims[0]) { trl_set_error("fused convs disagree on K (%s)", p.c_str()); return TRL_ERR_WEIGHTS; }
+            tot += (int)it->second->dims[1];
+        }
+        keep_alive.emplace_back((size_t)K * tot); const size_t iw = keep_alive.size() - 1;
+        keep_alive.emplace_back((size_t)tot);      const size_t isc = keep_alive.size() - 1;
+        keep_alive.emplace_back((size_t)tot);      const size_t ish = keep_alive.size() - 1;
+        int col = 0;
+        for (auto& p : parts) {
+            const Entry* e = idx[p + ".w"];
+            const float* src = (const float*)(b + e->offset);
+            const float* ssc = (const float*)(b + idx[p + ".scale"]->offset);
+            const float* ssh = (const float*)(b + idx[p + ".shift"]->offset);
+            const int co = (int)e->dims[1];
+            for (int k = 0; k < K; k++) for (int j = 0; j < co; j++) keep_alive[iw][(size_t)k * tot + col + j] = src[(size_t)k * co + j];
+            for (int j = 0; j < co; j++) { keep_alive[isc][col + j] = ssc[j]; keep_alive[ish][col + j] = ssh[j]; }
+            col += co;
+        }
+        add_mat(out + ".w", K, tot, keep_alive[iw].data());
+        add_vec(out + ".scale", tot, keep_alive[isc].data());
+        add_vec(out + ".shift", tot, keep_alive[ish].data());
+        return TRL_OK;
+    };
+    for (int i = 0; i < 5; i++) {
+        const std::string p = "facenet.repeat_1." + std::to_string(i);
+        TRL_CHECK(fuse_bconv(p + ".fused", {p + ".branch0", p + ".branch2.0", p + ".branch1.0"}));   // [b0 | b2.0 | b1.0]
+    }
+    for (int i = 0; i < 10; i++) {
+        const std::string p = "facenet.repeat_2." + std::to_string(i);
+        TRL_CHECK(fuse_bconv(p + ".fused", {p + ".branch0", p + ".branch1.0"}));
+    }
+    for (int i = 0; i < 6; i++) {
+        const std::string p = i < 5 ? "facenet.repeat_3." + std::to_string(i) : std::string("facenet.block8");
+        TRL_CHECK(fuse_bconv(p + ".fused", {p + ".branch0", p + ".branch1.0"}));
+    }
+    TRL_CHECK(fuse_bconv("facenet.mixed_7a.fused", {"facenet.mixed_7a.branch0.0", "facenet.mixed_7a.branch1.0", "facenet.mixed_7a.branch2.0"}));
     TRL_CHECK(merge_heads("pnet", {"conv4_1", "conv4_2"}));
     TRL_CHECK(merge_heads("rnet", {"dense5_1", "dense5_2"}));
     TRL_CHECK(merge_heads("onet", {"dense6_1", "dense6_2", "dense6_3"}));

@@ -50,6 +50,19 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
     float4 breg[BPT];
     const int kpad = (a.K + 15) & ~15;   // rows present in the zero-padded weight matrix
 
+    // Per-slot im2col cursor for the vector path: (channel, kx, ky) of the slot's current k, advanced by BK per
+    // chunk with a carry loop instead of two integer divisions per load (f32 MFMA shares the FP32 pipe with the
+    // VALU on gfx950, so every VALU instruction in the K loop is paid in matrix throughput).
+    int cur_c[APT], cur_kx[APT], cur_ky[APT];
+#pragma unroll
+    for (int i = 0; i < APT; i++) {
+        const int slot = tid + i * 256;
+        const int k = 4 * (slot / BM);
+        const int tap = k / a.Cin;
+        cur_c[i] = k - tap * a.Cin;
+        cur_ky[i] = tap / a.KW;
+        cur_kx[i] = tap - cur_ky[i] * a.KW;
+    }
     auto load_chunk = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < APT; i++) {
@@ -59,11 +72,9 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
                 const int k = k0 + 4 * (slot / BM);
                 if (VEC) {
                     if (k < a.K) {
-                        const int tap = k / a.Cin, c = k - tap * a.Cin;
-                        const int ky = tap / a.KW, kx = tap - ky * a.KW;
-                        const int iy = iy0 + ky, ix = ix0 + kx;
+                        const int iy = iy0 + cur_ky[i], ix = ix0 + cur_kx[i];
                         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                            v = *reinterpret_cast<const float4*>(xbase + ((size_t)iy * a.W + ix) * a.ldx + c);
+                            v = *reinterpret_cast<const float4*>(xbase + ((size_t)iy * a.W + ix) * a.ldx + cur_c[i]);
                     }
                 } else {
                     float t[4];
@@ -83,6 +94,13 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
                 }
             }
             areg[i] = v;
+            if (VEC) {   // advance the cursor to the next chunk
+                cur_c[i] += BK;
+                while (cur_c[i] >= a.Cin) {
+                    cur_c[i] -= a.Cin;
+                    if (++cur_kx[i] == a.KW) { cur_kx[i] = 0; ++cur_ky[i]; }
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < BPT; i++) {
@@ -189,27 +207,39 @@ int launch_cfg(const ConvArgs& a, bool vec, hipStream_t s) {
 }
 
 // ---- max pool -------------------------------------------------------------------------------
+template <int V>   // V channels per thread (4 when every stride / offset is a multiple of 4 floats)
 __global__ void maxpool_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx, int xoff,
                                int k, int st, float* __restrict__ y, int ldy, int yoff, int OH, int OW) {
-    const size_t total = (size_t)N * OH * OW * C;
+    const int CV = C / V;
+    const size_t total = (size_t)N * OH * OW * CV;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        size_t pix = idx / C;
+        const int c = (int)(idx % CV) * V;
+        size_t pix = idx / CV;
         const int ox = (int)(pix % OW); pix /= OW;
         const int oy = (int)(pix % OH);
         const int n = (int)(pix / OH);
-        float best = -INFINITY;
+        float best[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) best[j] = -INFINITY;
         for (int ky = 0; ky < k; ky++) {
             const int iy = oy * st + ky;
             if (iy >= H) break;
             for (int kx = 0; kx < k; kx++) {
                 const int ix = ox * st + kx;
                 if (ix >= W) break;
-                const float v = x[(((size_t)n * H + iy) * W + ix) * ldx + xoff + c];
-                best = v > best ? v : best;
+                const float* p = x + (((size_t)n * H + iy) * W + ix) * ldx + xoff + c;
+                if (V == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(p);
+                    best[0] = v.x > best[0] ? v.x : best[0]; best[1] = v.y > best[1] ? v.y : best[1];
+                    best[2 % V] = v.z > best[2 % V] ? v.z : best[2 % V]; best[3 % V] = v.w > best[3 % V] ? v.w : best[3 % V];
+                } else {
+                    best[0] = p[0] > best[0] ? p[0] : best[0];
+                }
             }
         }
-        y[(((size_t)n * OH + oy) * OW + ox) * ldy + yoff + c] = best;
+        float* q = y + (((size_t)n * OH + oy) * OW + ox) * ldy + yoff + c;
+        if (V == 4) *reinterpret_cast<float4*>(q) = make_float4(best[0], best[1 % V], best[2 % V], best[3 % V]);
+        else q[0] = best[0];
     }
 }
 
@@ -308,11 +338,14 @@ int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
 int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st, int ceil_mode,
                        float* y, int ldy, int yoff, int OH, int OW, hipStream_t s) {
     (void)ceil_mode;
-    const size_t total = (size_t)N * OH * OW * C;
+    const bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (xoff % 4 == 0) && (ldy % 4 == 0) && (yoff % 4 == 0) &&
+                    (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0);
+    const size_t total = (size_t)N * OH * OW * (v4 ? C / 4 : C);
     if (total == 0) return TRL_OK;
     size_t blocks = (total + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    maxpool_kernel<<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW);
+    if (blocks > 32768) blocks = 32768;
+    if (v4) maxpool_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW);
+    else maxpool_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }

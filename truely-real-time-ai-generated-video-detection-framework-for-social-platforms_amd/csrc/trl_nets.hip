@@ -81,32 +81,30 @@ struct Runner {
     }
 };
 
+// The 1x1 branches that read the block input run as one fused conv (weights concatenated at load time);
+// the concat buffer doubles as their scratch: a slice is only overwritten after its last reader has run.
 Act block35(Runner& R, const Act& x, const std::string& p) {
     Act cat = R.alloc(x.n, x.h, x.w, 96);
-    Act s0 = Runner::slice(cat, 0, 32), s1 = Runner::slice(cat, 32, 32), s2 = Runner::slice(cat, 64, 32);
-    R.bconv(x, p + ".branch0", 1, 1, 1, 1, 0, 0, &s0);
-    Act a = R.bconv(x, p + ".branch1.0", 1, 1, 1, 1, 0, 0);
-    R.bconv(a, p + ".branch1.1", 3, 3, 1, 1, 1, 1, &s1);
-    Act b = R.bconv(x, p + ".branch2.0", 1, 1, 1, 1, 0, 0);
-    Act b2 = R.bconv(b, p + ".branch2.1", 3, 3, 1, 1, 1, 1);
-    R.bconv(b2, p + ".branch2.2", 3, 3, 1, 1, 1, 1, &s2);
+    Act s1 = Runner::slice(cat, 32, 32), s2 = Runner::slice(cat, 64, 32);
+    R.bconv(x, p + ".fused", 1, 1, 1, 1, 0, 0, &cat);                 // [branch0 | branch2.0 | branch1.0]
+    Act b2 = R.bconv(s1, p + ".branch2.1", 3, 3, 1, 1, 1, 1);         // reads branch2.0 (cols 32:64)
+    R.bconv(s2, p + ".branch1.1", 3, 3, 1, 1, 1, 1, &s1);             // reads branch1.0 (64:96) -> final branch1 at 32:64
+    R.bconv(b2, p + ".branch2.2", 3, 3, 1, 1, 1, 1, &s2);             // final branch2 at 64:96
     return R.resid(cat, x, p + ".conv2d", 0.17f, true);
 }
 Act block17(Runner& R, const Act& x, const std::string& p) {
     Act cat = R.alloc(x.n, x.h, x.w, 256);
-    Act s0 = Runner::slice(cat, 0, 128), s1 = Runner::slice(cat, 128, 128);
-    R.bconv(x, p + ".branch0", 1, 1, 1, 1, 0, 0, &s0);
-    Act a = R.bconv(x, p + ".branch1.0", 1, 1, 1, 1, 0, 0);
-    Act a2 = R.bconv(a, p + ".branch1.1", 1, 7, 1, 1, 0, 3);
+    Act s1 = Runner::slice(cat, 128, 128);
+    R.bconv(x, p + ".fused", 1, 1, 1, 1, 0, 0, &cat);                 // [branch0 | branch1.0]
+    Act a2 = R.bconv(s1, p + ".branch1.1", 1, 7, 1, 1, 0, 3);
     R.bconv(a2, p + ".branch1.2", 7, 1, 1, 1, 3, 0, &s1);
     return R.resid(cat, x, p + ".conv2d", 0.10f, true);
 }
 Act block8(Runner& R, const Act& x, const std::string& p, float scale, bool relu) {
     Act cat = R.alloc(x.n, x.h, x.w, 384);
-    Act s0 = Runner::slice(cat, 0, 192), s1 = Runner::slice(cat, 192, 192);
-    R.bconv(x, p + ".branch0", 1, 1, 1, 1, 0, 0, &s0);
-    Act a = R.bconv(x, p + ".branch1.0", 1, 1, 1, 1, 0, 0);
-    Act a2 = R.bconv(a, p + ".branch1.1", 1, 3, 1, 1, 0, 1);
+    Act s1 = Runner::slice(cat, 192, 192);
+    R.bconv(x, p + ".fused", 1, 1, 1, 1, 0, 0, &cat);                 // [branch0 | branch1.0]
+    Act a2 = R.bconv(s1, p + ".branch1.1", 1, 3, 1, 1, 0, 1);
     R.bconv(a2, p + ".branch1.2", 3, 1, 1, 1, 1, 0, &s1);
     return R.resid(cat, x, p + ".conv2d", scale, relu);
 }
@@ -148,12 +146,11 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
         Act cat = R.alloc(n, OH, OW, 1792);
         Act s0 = Runner::slice(cat, 0, 384), s1 = Runner::slice(cat, 384, 256), s2 = Runner::slice(cat, 640, 256),
             s3 = Runner::slice(cat, 896, 896);
-        Act a = R.bconv(x, f + "mixed_7a.branch0.0", 1, 1, 1, 1, 0, 0);
-        R.bconv(a, f + "mixed_7a.branch0.1", 3, 3, 2, 2, 0, 0, &s0);
-        a = R.bconv(x, f + "mixed_7a.branch1.0", 1, 1, 1, 1, 0, 0);
-        R.bconv(a, f + "mixed_7a.branch1.1", 3, 3, 2, 2, 0, 0, &s1);
-        a = R.bconv(x, f + "mixed_7a.branch2.0", 1, 1, 1, 1, 0, 0);
-        Act a2 = R.bconv(a, f + "mixed_7a.branch2.1", 3, 3, 1, 1, 1, 1);
+        Act t = R.bconv(x, f + "mixed_7a.fused", 1, 1, 1, 1, 0, 0);   // [branch0.0 | branch1.0 | branch2.0]
+        Act t0 = Runner::slice(t, 0, 256), t1 = Runner::slice(t, 256, 256), t2 = Runner::slice(t, 512, 256);
+        R.bconv(t0, f + "mixed_7a.branch0.1", 3, 3, 2, 2, 0, 0, &s0);
+        R.bconv(t1, f + "mixed_7a.branch1.1", 3, 3, 2, 2, 0, 0, &s1);
+        Act a2 = R.bconv(t2, f + "mixed_7a.branch2.1", 3, 3, 1, 1, 1, 1);
         R.bconv(a2, f + "mixed_7a.branch2.2", 3, 3, 2, 2, 0, 0, &s2);
         R.pool(x, 3, 2, 0, &s3);
         x = cat;
