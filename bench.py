@@ -46,7 +46,9 @@ def cpu_baseline(frames_np, threads):
     orc = Oracle(truely_amd.weights.pack_state_dicts(*sds))
     t0 = time.time()
     done = 0
-    for fr in frames_np:
+    budget = float(os.environ.get("TRUELY_CPU_BASELINE_SECONDS", "20"))
+    while time.time() - t0 < budget:
+        fr = frames_np[done % len(frames_np)]
         boxes, _ = ref.detect(fr)
         if boxes is not None and len(boxes) > 0:
             b = boxes[0].astype(int)
@@ -55,12 +57,10 @@ def cpu_baseline(frames_np, threads):
                 face = orc.resize_linear_u8(fr, y0, y1, x0, x1)     # cv2.resize stand-in (no OpenCV here)
                 ref.embed(face)
         done += 1
-        if time.time() - t0 > 25 and done >= 4:
-            break
     dt = time.time() - t0
     return {"value": round(done / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{done} of the same synthetic 720p frames, torch-CPU fp32 restatement of the reference "
-                      f"path, one frame at a time like server/model.py ({dt:.1f} s)"}
+            "sample": f"{done} frames of the same synthetic 720p clip in {dt:.1f} s, torch-CPU fp32 restatement of the "
+                      f"reference path (oracle/torch_ref.py), one frame at a time like server/model.py:42-59"}
 
 
 def main():
@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pnet-mode", type=int, default=None)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo to rehearse the N>1 path on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,10 +84,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share one GPU under gloo
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     n = args.batch
     frames_np = truely_amd.synthetic.synthetic_frames(n, H, W, seed=rank, faces=1)
@@ -111,11 +117,12 @@ def main():
     for _ in range(args.warmup):
         out, d = step()
     fence()
-    pnet_ms = 0.0
+    pnet_ms = pyr_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, d = step()
-        pnet_ms += eng.timings()["pnet_ms"]
+        tm = eng.timings()
+        pnet_ms += tm["pnet_ms"]; pyr_ms += tm["pyramid_ms"]
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -129,6 +136,11 @@ def main():
         launches = max(1, tm["pnet_launches"])
         pnet_s = pnet_ms / 1e3 / args.steps          # PNet time per step (HIP events on the stream, inside the library)
         achieved = 2.0 * macs / pnet_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "round1_pnet_traffic.json")
+        if eng.cfg.pnet_mode == 0 and n == BATCH and os.path.exists(tpath):
+            # HBM bytes per launch of k_pnet_fused from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
         res = {
             "metric": "frames/sec (detect+embed+drift) 720p", "value": round(n * world * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -140,13 +152,14 @@ def main():
                        "pnet_path": "fused" if eng.cfg.pnet_mode == 0 else "generic layers",
                        "parallelism": f"frame-sharded x{world}, 1 all-gather of embeddings" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "PNet pyramid (dominant: 83% of conv FLOPs at 720p)",
-                         "flop_per_step": 2.0 * macs, "kernel_ms_per_step": round(pnet_s * 1e3, 3), "launches_per_step": launches},
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "k_pnet_fused (PNet over the pyramid: 83% of the conv FLOPs at 720p)",
+                         "flop_per_step": 2.0 * macs, "kernel_ms_per_step": round(pnet_s * 1e3, 3), "launches_per_step": launches,
+                         "pyramid_ms_per_step": round(pyr_ms / args.steps, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, len(os.sched_getaffinity(0)))
-            res["cpu_baseline"] = cpu_baseline(frames_np[:16], threads)
+            res["cpu_baseline"] = cpu_baseline(frames_np, threads)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
