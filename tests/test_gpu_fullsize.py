@@ -1,0 +1,91 @@
+"""GPU tests at BASELINE.json's full sizes through size-independent properties, plus the larger
+configurations (1080p multi-face, 4K) on single frames against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import truely_amd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def clip720():
+    return truely_amd.synthetic.synthetic_frames(256, 720, 1280, seed=0)
+
+
+def test_full_batch_determinism_and_batch_independence(engine, clip720):
+    """configs[1] at full size: candidates are appended with atomics in arbitrary order, yet every output is
+    reproducible bit for bit, and a frame's result does not depend on which batch it travels in."""
+    a = engine.detect_embed(clip720)
+    b = engine.detect_embed(clip720)
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        assert torch.equal(a[k], b[k]), k
+    assert int(a["valid"].sum()) >= 200                     # "1-face frames": almost every frame yields a face
+    idx = [0, 17, 101, 255]
+    sub = engine.detect_embed(clip720[idx])
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        assert torch.equal(sub[k], a[k][idx]), k
+    rev = engine.detect_embed(clip720[::-1].copy())          # reversed frame order
+    assert torch.equal(rev["emb"].flip(0), a["emb"]) and torch.equal(rev["rect"].flip(0), a["rect"])
+    # embeddings are unit vectors; invalid rows are exactly zero
+    nrm = a["emb"].norm(dim=1)
+    v = a["valid"].bool()
+    assert torch.allclose(nrm[v], torch.ones_like(nrm[v]), atol=1e-5) and (nrm[~v] == 0).all()
+
+
+def test_full_batch_sampled_against_oracle(engine, oracle, clip720):
+    out = engine.detect_embed(clip720)
+    for i in (3, 128, 250):
+        ref = oracle.detect_embed(clip720[i:i + 1])
+        assert np.array_equal(out["rect"][i].cpu().numpy(), ref["rect"][0])
+        assert out["valid"][i].item() == ref["valid"][0]
+        assert np.array_equal(out["emb"][i].cpu().numpy(), ref["emb"][0])
+
+
+def test_drift_is_a_function_of_time_order_only(engine, clip720):
+    """Splitting the clip into shards and concatenating embeddings (the multi-GPU path) changes nothing."""
+    full = engine.detect_embed(clip720[:64])
+    parts = [engine.detect_embed(clip720[i:i + 16]) for i in range(0, 64, 16)]
+    emb = torch.cat([p["emb"] for p in parts]); valid = torch.cat([p["valid"] for p in parts])
+    d0 = engine.drift_score(full["emb"], full["valid"], 256, 30)
+    d1 = engine.drift_score(emb, valid, 256, 30)
+    assert d0["score"] == d1["score"] and torch.equal(d0["sims"], d1["sims"]) and torch.equal(d0["flags"], d1["flags"])
+
+
+@pytest.mark.parametrize("H,W,faces,seed", [(1080, 1920, -1, 31), (2160, 3840, 1, 32)])
+def test_large_frames_against_oracle(engine, blob, oracle, H, W, faces, seed):
+    """configs[2] (1080p, 3-5 faces) and configs[4] (4K, min_face_size=20 -> 14 pyramid levels), fp32 path."""
+    if H > 1080:   # a 4K frame has ~3x the candidates of the default list capacity: use the largest lists
+        from truely_amd.engine import Engine
+        engine = Engine(blob, cap_level=3072, cap_frame=3072)
+    fr = truely_amd.synthetic.synthetic_frames(1, H, W, seed=seed, faces=faces)
+    out = engine.detect_embed(fr)
+    _b, _p, tr = oracle.detect(fr[0], trace=True)
+    cand, keep = engine.level_counts(0)
+    assert cand == tr["n_cand_scale"] and keep == tr["n_keep_scale"]
+    assert len(cand) == (12 if H == 1080 else 14)
+    for s in (1, 2, 3):
+        assert np.array_equal(engine.stage_boxes(s, 0), tr[f"boxes{s}"])
+    ref = oracle.detect_embed(fr)
+    assert np.array_equal(out["rect"].cpu().numpy(), ref["rect"]) and np.array_equal(out["emb"].cpu().numpy(), ref["emb"])
+
+
+def test_frames_without_candidates(engine, oracle):
+    """A flat frame: PNet fires nowhere or NMS leaves nothing -> detect() is None, valid = 0, zero embedding."""
+    fr = np.full((2, 240, 320, 3), 127, np.uint8)
+    out = engine.detect_embed(fr)
+    ref = oracle.detect_embed(fr)
+    assert np.array_equal(out["valid"].cpu().numpy(), ref["valid"])
+    assert np.array_equal(out["emb"].cpu().numpy(), ref["emb"])
+    d = engine.drift_score(out["emb"], out["valid"], 8, 30)
+    assert d["score"] == oracle.drift_score(ref["emb"], ref["valid"], 8, 30)["score"]
+
+
+def test_minimum_frame_size(engine, oracle):
+    """12x12 is the smallest frame with a pyramid level (min(h,w)*0.6 >= 12 fails below 20 px)."""
+    for (H, W) in [(20, 20), (21, 37)]:
+        fr = truely_amd.synthetic.synthetic_frames(2, H, W, seed=5)
+        out = engine.detect_embed(fr)
+        ref = oracle.detect_embed(fr)
+        assert np.array_equal(out["valid"].cpu().numpy(), ref["valid"]) and np.array_equal(out["rect"].cpu().numpy(), ref["rect"])
