@@ -80,20 +80,40 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                 while (oxb < S && (((oxb + 1) * iw + S - 1) / S - xsa) * 3 <= COLCAP) oxb++;
                 const int xeb = (oxb * iw + S - 1) / S;
                 const int seg_bytes = (xeb - xsa) * 3;
-                for (int c0 = 0; c0 < seg_bytes; c0 += 256) {
-                    const int b = c0 + 4 * lane;
-                    if (b < seg_bytes) {
-                        unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-                        long long o = fbyte0 + ((long long)(y0 + ys) * W + x0 + xsa) * 3 + b;
-#pragma unroll 4
-                        for (int yy = ys; yy < ye; yy++, o += (long long)W * 3) {
-                            const long long dw = o >> 2;
-                            const unsigned w0 = base32[dw];
-                            const unsigned w1 = base32[dw < last_dw ? dw + 1 : last_dw];
-                            const unsigned v = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)(o & 3));
-                            s0 += v & 0xFFu; s1 += (v >> 8) & 0xFFu; s2 += (v >> 16) & 0xFFu; s3 += v >> 24;
-                        }
-                        colbuf[b] = s0; colbuf[b + 1] = s1; colbuf[b + 2] = s2; colbuf[b + 3] = s3;
+                // four 256-byte chunks x four source rows per pass: 32 independent dword loads are in flight before
+                // any is consumed (the crop is latency-bound: one wave owns the row, nothing else hides the latency)
+                const long long o_safe = fbyte0 + ((long long)(y0 + ys) * W + x0 + xsa) * 3;
+                const long long row_pitch = (long long)W * 3;
+                for (int c0 = 0; c0 < seg_bytes; c0 += 1024) {
+                    unsigned sum[4][4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { sum[c][0] = 0; sum[c][1] = 0; sum[c][2] = 0; sum[c][3] = 0; }
+                    for (int yy = ys; yy < ye; yy += 4) {
+                        unsigned lo[4][4], hi[4][4], shv[4][4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                const int b = c0 + 256 * c + 4 * lane;
+                                const bool act = (yy + r < ye) && (b < seg_bytes);
+                                const long long o = act ? o_safe + (long long)(yy + r - ys) * row_pitch + b : o_safe;
+                                const long long dw = o >> 2;
+                                lo[r][c] = base32[dw];
+                                hi[r][c] = base32[dw < last_dw ? dw + 1 : last_dw];
+                                shv[r][c] = act ? (unsigned)(o & 3) : 4u;   // 4 = inactive marker
+                            }
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                const unsigned v = shv[r][c] < 4u ? __builtin_amdgcn_alignbyte(hi[r][c], lo[r][c], shv[r][c]) : 0u;
+                                sum[c][0] += v & 0xFFu; sum[c][1] += (v >> 8) & 0xFFu; sum[c][2] += (v >> 16) & 0xFFu; sum[c][3] += v >> 24;
+                            }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int b = c0 + 256 * c + 4 * lane;
+                        if (b < seg_bytes) { colbuf[b] = sum[c][0]; colbuf[b + 1] = sum[c][1]; colbuf[b + 2] = sum[c][2]; colbuf[b + 3] = sum[c][3]; }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
