@@ -57,6 +57,7 @@ int trl_destroy(trl_ctx* c) {
     if (c->wdev) hipFree(c->wdev);
     if (c->arena.base) hipFree(c->arena.base);
     if (c->scratch.base) hipFree(c->scratch.base);
+    if (c->sims_tmp.base) hipFree(c->sims_tmp.base);
     if (c->pyr_tab) hipFree(c->pyr_tab);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->ev_call0) hipEventDestroy(c->ev_call0);
@@ -327,7 +328,12 @@ int trl_drift_score(trl_ctx* c, const float* d_emb, const uint8_t* d_valid, int 
                     uint8_t* d_flags, int32_t* d_result, void* stream) {
     if (!c || !d_emb || !d_valid || !d_result || n < 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
     TRL_HIP(hipSetDevice(c->cfg.device));
-    return trl_launch_drift(d_emb, d_valid, n, frame_count, fps, d_sims, d_flags, d_result, (hipStream_t)stream);
+    float* sims = d_sims;
+    if (!sims) {   // the scan needs the similarities even when the caller does not want them
+        TRL_CHECK(trl_ensure(c, c->sims_tmp, (size_t)(n > 0 ? n : 1) * sizeof(float)));
+        sims = (float*)c->sims_tmp.base;
+    }
+    return trl_launch_drift(d_emb, d_valid, n, frame_count, fps, sims, d_flags, d_result, (hipStream_t)stream);
 }
 
 // ---- inspection hooks ----------------------------------------------------------------------------------

@@ -39,6 +39,7 @@ struct trl_ctx {
     std::unordered_map<std::string, DevV> V;
     Arena arena;                     // per-call persistent blocks (cascade lists)
     Arena scratch;                   // transient activations; only ever grown while empty
+    Arena sims_tmp;                  // similarities when trl_drift_score is called with d_sims == NULL
     int32_t* h_pinned = nullptr;     // small pinned host scratch
     CascadeBufs cb;
     LevelGeom lv[32];

@@ -269,36 +269,57 @@ __global__ __launch_bounds__(64) void l2norm512_kernel(const float* __restrict__
     for (int i = 0; i < 8; i++) o[lane + 64 * i] = v[lane + 64 * i] / nrm;
 }
 
-// server/model.py:60-66,70,75,86-95 -- one wave walks the sampled frames in time order.
-__global__ __launch_bounds__(64) void drift_kernel(const float* __restrict__ emb, const uint8_t* __restrict__ valid, int n,
-                                                   long long frame_count, int fps, float* __restrict__ sims,
-                                                   uint8_t* __restrict__ flags, int32_t* __restrict__ result) {
-    const int lane = threadIdx.x;
-    const float thr_sim = 0.99f;   // model.py:16
-    const int thr_frames = 15;     // model.py:17
-    int run = 0, hits = 0, prev = -1;
-    float nprev = 0.f;
-    for (int i = 0; i < n; i++) {
-        float sim = 2.0f;
-        uint8_t flag = 0;
-        if (valid[i]) {   // wave-uniform
+// server/model.py:60-61 -- cosine similarity of every embedded frame with the previous embedded frame.
+// One wave per sampled frame; the three 512-long dots use the oracle's fixed lane order (trl_wave_dot512).
+__global__ __launch_bounds__(256) void drift_sims_kernel(const float* __restrict__ emb, const uint8_t* __restrict__ valid, int n,
+                                                         float* __restrict__ sims) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float sim = 2.0f;                       // 2.0 = "no comparison happened"
+    if (valid[i]) {
+        int prev = i - 1;
+        while (prev >= 0 && !valid[prev]) prev--;   // frames without a face neither compare nor replace `previous` (model.py:48-75)
+        if (prev >= 0) {
             const float* cur = emb + (size_t)i * 512;
-            const float ncur = sqrtf(trl_wave_dot512(cur, cur, lane));
-            if (prev >= 0) {
-                const float d = trl_wave_dot512(cur, emb + (size_t)prev * 512, lane);
-                sim = d / (ncur * nprev);
-                run = (sim < thr_sim) ? run + 1 : 0;
-                if (run > thr_frames) { hits++; flag = 1; }
-            }
-            prev = i;
-            nprev = ncur;
-        }
-        if (lane == 0) {
-            if (sims) sims[i] = sim;
-            if (flags) flags[i] = flag;
+            const float* pv = emb + (size_t)prev * 512;
+            const float d = trl_wave_dot512(cur, pv, lane);
+            const float na = sqrtf(trl_wave_dot512(cur, cur, lane)), nb = sqrtf(trl_wave_dot512(pv, pv, lane));
+            sim = d / (na * nb);
         }
     }
-    if (lane == 0) {
+    if (lane == 0) sims[i] = sim;
+}
+
+// server/model.py:62-66,70,86-95 -- the run-length state machine is a scan over the similarities: staged in
+// LDS in chunks, walked by one lane, then the score in double like the reference's Python floats.
+__global__ __launch_bounds__(256) void drift_scan_kernel(const float* __restrict__ sims, int n, long long frame_count, int fps,
+                                                         uint8_t* __restrict__ flags, int32_t* __restrict__ result) {
+    __shared__ float sh[4096];
+    __shared__ uint8_t fl[4096];
+    const float thr_sim = 0.99f;   // model.py:16
+    const int thr_frames = 15;     // model.py:17
+    int run = 0, hits = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int m = (n - base) < 4096 ? (n - base) : 4096;
+        for (int t = threadIdx.x; t < m; t += blockDim.x) sh[t] = sims[base + t];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int t = 0; t < m; t++) {
+                const float sim = sh[t];
+                uint8_t f = 0;
+                if (sim <= 1.5f) {          // a comparison happened
+                    run = (sim < thr_sim) ? run + 1 : 0;
+                    if (run > thr_frames) { hits++; f = 1; }
+                }
+                fl[t] = f;
+            }
+        }
+        __syncthreads();
+        if (flags) for (int t = threadIdx.x; t < m; t += blockDim.x) flags[base + t] = fl[t];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
         int score = 0;
         long long total = 0;
         if (frame_count > 0 && fps > 0) {
@@ -366,7 +387,11 @@ int trl_launch_l2norm512(const float* x, const uint8_t* valid, int n, float* y, 
 
 int trl_launch_drift(const float* emb, const uint8_t* valid, int n, long long frame_count, int fps, float* sims,
                      uint8_t* flags, int32_t* result, hipStream_t s) {
-    drift_kernel<<<1, 64, 0, s>>>(emb, valid, n, frame_count, fps, sims, flags, result);
+    if (n > 0) {
+        drift_sims_kernel<<<(n + 3) / 4, 256, 0, s>>>(emb, valid, n, sims);
+        TRL_LAUNCH_CHECK();
+    }
+    drift_scan_kernel<<<1, 256, 0, s>>>(sims, n, frame_count, fps, flags, result);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
