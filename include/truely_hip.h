@@ -100,6 +100,13 @@ int  trl_drift_score(trl_ctx* ctx, const float* d_emb, const uint8_t* d_valid, i
                      long long frame_count, int fps, float* d_sims, uint8_t* d_flags,
                      int32_t* d_result, void* stream);
 
+/* SURVEY 8(f)-1, device-side ingest in place of the CPU decode + sampling at server/model.py:43,46:
+ * d_nv12 holds n_in decoder-output frames (NV12: H*W luma bytes, then H/2 rows of interleaved U,V);
+ * frames 0, step, 2*step, ... are converted to u8 BGR [n_out][H][W][3] (OpenCV's integer BT.601
+ * limited-range arithmetic) ready for trl_detect_embed.  step = max(1, int(fps / 7)) (model.py:40). */
+int  trl_ingest_nv12(trl_ctx* ctx, const uint8_t* d_nv12, int n_in, int H, int W, int step,
+                     uint8_t* d_bgr, int* n_out, void* stream);
+
 /* ---- inspection hooks used by the parity tests (stage-by-stage vs the oracle) ------------- */
 /* Boxes of one frame after cascade stage 1/2/3 of the LAST trl_mtcnn_detect / trl_detect_embed
  * call (host output, rows of 5: x1,y1,x2,y2,score).  Returns the count in *n_out. */

@@ -128,6 +128,12 @@ class Oracle:
         self.lib.orc_facenet(C.c_void_p(self.ctx), _p(x), n, H, W, _p(emb))
         return emb
 
+    def nv12_to_bgr(self, nv12, H, W):
+        nv12 = np.ascontiguousarray(nv12, np.uint8)
+        out = np.empty((H, W, 3), np.uint8)
+        self.lib.orc_nv12_to_bgr(_p(nv12, C.c_uint8), int(H), int(W), _p(out, C.c_uint8))
+        return out
+
     # ---- cascade ----
     def detect(self, frame, max_out=64, trace=False):
         frame = np.ascontiguousarray(frame, np.uint8); H, W = frame.shape[:2]

@@ -976,3 +976,25 @@ int orc_drift_score(const float* emb, const uint8_t* valid, int n, long frame_co
     if (r > 100) r = 100;
     return r; /* model.py:95 */
 }
+
+/* ------------------------------------------------------------------------- */
+/* SURVEY 8(f)-1 ingest: NV12 -> BGR, OpenCV cvtColor(COLOR_YUV2BGR_NV12) integer BT.601            */
+/* (RECALLED: modules/imgproc/src/color_yuv.simd.hpp uvToRGBuv / yRGBuvToRGBA, 20-bit fixed point). */
+/* ------------------------------------------------------------------------- */
+void orc_nv12_to_bgr(const uint8_t* nv12, int H, int W, uint8_t* bgr) {
+    const int CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527, SH = 20;
+    const uint8_t* yp = nv12;
+    const uint8_t* uvp = nv12 + (size_t)H * W;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const int u = uvp[(size_t)(y / 2) * W + (x / 2) * 2] - 128, v = uvp[(size_t)(y / 2) * W + (x / 2) * 2 + 1] - 128;
+            const int ruv = (1 << (SH - 1)) + CVR * v, guv = (1 << (SH - 1)) + CVG * v + CUG * u, buv = (1 << (SH - 1)) + CUB * u;
+            int yy = yp[(size_t)y * W + x] - 16;
+            yy = (yy > 0 ? yy : 0) * CY;
+            int b = (yy + buv) >> SH, g = (yy + guv) >> SH, r = (yy + ruv) >> SH;
+            uint8_t* o = bgr + ((size_t)y * W + x) * 3;
+            o[0] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+            o[1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
+            o[2] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+}

@@ -107,6 +107,9 @@ int   orc_detect_embed(const orc_ctx*, const uint8_t* frames, int n, int H, int 
 int   orc_drift_score(const float* emb, const uint8_t* valid, int n, long frame_count, int fps,
                       float* sims_out, uint8_t* flag_out, int* final_run, int* hits);
 
+/* one NV12 frame (H*W luma + H/2 x W interleaved UV) -> BGR, OpenCV integer BT.601 */
+void  orc_nv12_to_bgr(const uint8_t* nv12, int H, int W, uint8_t* bgr);
+
 #ifdef __cplusplus
 }
 #endif

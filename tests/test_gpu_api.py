@@ -107,3 +107,17 @@ def test_bad_arguments_are_rejected(engine):
         engine.detect_embed(np.zeros((1, 8, 8, 3), np.uint8))      # smaller than the 12x12 PNet field
     with pytest.raises(TrlError):
         engine.facenet_embed(torch.zeros(1, 40, 40, 3))            # too small for the stem
+
+
+def test_nv12_ingest_with_sampling(engine, oracle):
+    """NV12 -> BGR of every step-th frame on the device equals the oracle per frame."""
+    rng = np.random.default_rng(12)
+    n, H, W, step = 9, 48, 64, 4
+    nv12 = rng.integers(0, 256, (n, H * W * 3 // 2), dtype=np.uint8)
+    nv12[0, :16] = [0, 255, 16, 235, 15, 17, 234, 236, 128, 1, 254, 100, 200, 50, 75, 3]   # range edges
+    out = engine.ingest_nv12(nv12, H, W, step).cpu().numpy()
+    assert out.shape == (3, H, W, 3)                                    # frames 0, 4, 8 (model.py:46)
+    for j, i in enumerate(range(0, n, step)):
+        assert np.array_equal(out[j], oracle.nv12_to_bgr(nv12[i], H, W)), i
+    with pytest.raises(Exception):
+        engine.ingest_nv12(nv12[:, :-3], H, W, step)

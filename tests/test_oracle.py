@@ -197,3 +197,24 @@ def test_score_run_resets_on_similar_frame(oracle):
     assert d["run"] == 29                                 # comparisons 31..59
     assert d["hits"] == (29 - 15) + (29 - 15)             # runs of 29 before and 29 after the reset
     assert oracle.drift_score(e[:0], np.zeros(0, np.uint8), 0, 30)["score"] == 0   # model.py:83-85
+
+
+def test_nv12_to_bgr_known_values(oracle):
+    """BT.601 limited range: (Y,U,V) = (16,128,128) -> black, (235,128,128) -> white, saturation at the ends."""
+    H, W = 2, 4
+    def frame(y, u, v):
+        return np.array([y] * (H * W) + [u, v] * (W // 2), np.uint8)
+    assert (oracle.nv12_to_bgr(frame(16, 128, 128), H, W) == 0).all()
+    assert (oracle.nv12_to_bgr(frame(235, 128, 128), H, W) == 255).all()
+    assert (oracle.nv12_to_bgr(frame(0, 128, 128), H, W) == 0).all()
+    px = oracle.nv12_to_bgr(frame(81, 90, 240), H, W)[0, 0]           # BT.601 "red": B,G,R
+    assert px[2] >= 250 and px[0] <= 5 and px[1] <= 5
+    # against the floating-point BT.601 definition within 1 LSB
+    rng = np.random.default_rng(2)
+    nv = rng.integers(16, 236, (8 * 8 * 3 // 2,), dtype=np.uint8)
+    got = oracle.nv12_to_bgr(nv, 8, 8).astype(np.float64)
+    y = nv[:64].reshape(8, 8).astype(np.float64) - 16
+    uv = nv[64:].reshape(4, 4, 2).astype(np.float64) - 128
+    u = np.repeat(np.repeat(uv[..., 0], 2, 0), 2, 1); v = np.repeat(np.repeat(uv[..., 1], 2, 0), 2, 1)
+    ref = np.stack([1.164 * y + 2.018 * u, 1.164 * y - 0.813 * v - 0.391 * u, 1.164 * y + 1.596 * v], -1).clip(0, 255)
+    assert np.abs(got - ref).max() <= 1.0

@@ -103,6 +103,21 @@ class Engine:
                                              _ptr(out["valid"]), _ptr(out["emb"]), self._stream()))
         return out
 
+    # NV12 decoder output -> sampled BGR batch on the device (model.py:43,46)
+    def ingest_nv12(self, nv12, H: int, W: int, step: int) -> torch.Tensor:
+        if isinstance(nv12, np.ndarray):
+            nv12 = torch.from_numpy(np.ascontiguousarray(nv12))
+        nv12 = nv12.to(self.device).contiguous()
+        if nv12.dtype != torch.uint8 or nv12.dim() != 2 or nv12.shape[1] != H * W * 3 // 2:
+            raise ValueError("nv12 must be uint8 (n, H*W*3/2)")
+        n_in = int(nv12.shape[0])
+        n_out = (n_in + step - 1) // step
+        out = torch.empty((n_out, H, W, 3), dtype=torch.uint8, device=self.device)
+        k = C.c_int()
+        _lib.check(self.lib.trl_ingest_nv12(self._h, _ptr(nv12), n_in, H, W, int(step), _ptr(out), C.byref(k), self._stream()))
+        assert k.value == n_out
+        return out
+
     # server/model.py:60-66,86-95
     def drift_score(self, emb: torch.Tensor, valid: torch.Tensor, frame_count: int, fps: int):
         emb = emb.to(self.device, torch.float32).contiguous()
