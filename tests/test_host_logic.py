@@ -124,3 +124,41 @@ def test_bench_flop_model_matches_survey():
     import bench
     assert abs(bench.pnet_macs(720, 1280) / 1e6 - 1171.4) < 0.1
     assert abs(bench.pnet_macs(360, 640) / 1e6 - 281.2) < 0.1
+
+
+def test_analysis_service_keeps_event_loop_free():
+    """requests queue on one worker, in order, while the event loop keeps running."""
+    import asyncio
+    import time
+    from truely_amd.service import AnalysisService
+    order = []
+
+    def fake_run(a, b):
+        time.sleep(0.05)
+        order.append(a)
+        if a == "boom":
+            raise RuntimeError("decode failed")
+        return len(a)
+
+    svc = AnalysisService(run_fn=fake_run)
+
+    async def main():
+        ticks = 0
+
+        async def ticker():
+            nonlocal ticks
+            for _ in range(20):
+                await asyncio.sleep(0.005)
+                ticks += 1
+
+        t = asyncio.create_task(ticker())
+        res = await asyncio.gather(svc.analyze("a", "o"), svc.analyze("bbb", "o"), svc.analyze("cc", "o"))
+        with pytest.raises(RuntimeError):
+            await svc.analyze("boom", "o")
+        await t
+        return res, ticks
+
+    res, ticks = asyncio.run(main())
+    svc.close()
+    assert res == [1, 3, 2] and order[:3] == ["a", "bbb", "cc"]      # FIFO, one at a time
+    assert ticks == 20 and svc.completed == 3                       # the loop was never blocked
