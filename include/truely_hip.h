@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 1
+#define TRL_ABI_VERSION 2
 
 typedef enum {
     TRL_OK = 0,
@@ -53,6 +53,9 @@ typedef struct {
     int    cap_frame;       /* max candidates per frame entering R-Net                   [4096] */
     int    max_faces;       /* max boxes returned per frame by trl_mtcnn_detect          [64]   */
     int    pnet_mode;       /* 0 = fused PNet kernel, 1 = generic layer path (validation) */
+    int    embed_mode;      /* 0 = reference: 80x80 INTER_LINEAR crop, BGR, /255 (model.py:41,57-58)  [default]
+                             * 1 = SURVEY 8(f)-4 native mode: facenet-pytorch extract_face (160x160 area
+                             *     resample, .byte(), (x-127.5)/128), channel order kept; 2 = same, BGR->RGB */
 } trl_config;
 
 int  trl_abi_version(void);

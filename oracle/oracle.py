@@ -170,6 +170,21 @@ class Oracle:
             out["faces"] = faces
         return out
 
+    def detect_embed_mode(self, frames, mode):
+        frames = np.ascontiguousarray(frames, np.uint8); n, H, W, _ = frames.shape
+        box = np.zeros((n, 4), np.float32); prob = np.zeros((n,), np.float32)
+        rect = np.zeros((n, 4), np.int32); valid = np.zeros((n,), np.uint8); emb = np.zeros((n, 512), np.float32)
+        self.lib.orc_detect_embed_mode(C.c_void_p(self.ctx), _p(frames, C.c_uint8), n, H, W, C.byref(self.params), int(mode),
+                                       _p(box), _p(prob), _p(rect, C.c_int32), _p(valid, C.c_uint8), _p(emb))
+        return {"box": box, "prob": prob, "rect": rect, "valid": valid, "emb": emb}
+
+    def crop_area_std(self, img, rect, S=160, rgb=False):
+        img = np.ascontiguousarray(img, np.uint8); H, W = img.shape[:2]
+        out = np.empty((S, S, 3), np.float32)
+        x0, y0, x1, y1 = (int(v) for v in rect)
+        self.lib.orc_crop_area_std(_p(img, C.c_uint8), H, W, x0, y0, x1, y1, int(S), int(bool(rgb)), _p(out))
+        return out
+
     def drift_score(self, emb, valid, frame_count, fps):
         emb = np.ascontiguousarray(emb, np.float32); valid = np.ascontiguousarray(valid, np.uint8)
         n = len(valid)

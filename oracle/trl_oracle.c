@@ -886,6 +886,61 @@ void orc_facenet(const orc_ctx* c, const float* in, int n, int H, int W, float* 
 /* ------------------------------------------------------------------------- */
 /* model.py:47-59 on a batch of sampled frames                                */
 /* ------------------------------------------------------------------------- */
+/* SURVEY 8(f)-4 native mode: facenet_pytorch extract_face() for tensor input (RECALLED: crop_resize ->
+ * imresample(area) -> .byte() truncation), then fixed_image_standardization (x-127.5)/128, optional BGR->RGB. */
+void orc_crop_area_std(const uint8_t* img, int H, int W, int x0, int y0, int x1, int y1, int S, int rgb, float* out) {
+    (void)H;
+    const int ih = y1 - y0, iw = x1 - x0;
+    for (int oy = 0; oy < S; oy++) {
+        const int ys = (int)(((long)oy * ih) / S), ye = (int)((((long)oy + 1) * ih + S - 1) / S);
+        for (int ox = 0; ox < S; ox++) {
+            const int xs = (int)(((long)ox * iw) / S), xe = (int)((((long)ox + 1) * iw + S - 1) / S);
+            uint32_t s[3] = {0, 0, 0};
+            for (int y = ys; y < ye; y++) {
+                const uint8_t* p = img + ((size_t)(y0 + y) * W + x0 + xs) * 3;
+                for (int x = xs; x < xe; x++, p += 3) { s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; }
+            }
+            const float kh = (float)(ye - ys), kw = (float)(xe - xs);
+            for (int c = 0; c < 3; c++) {
+                const float mean = (float)s[c] / kh / kw;
+                const float byte = (float)(uint8_t)mean;              /* .byte(): truncation toward zero */
+                out[((size_t)oy * S + ox) * 3 + (rgb ? 2 - c : c)] = (byte - 127.5f) / 128.0f;
+            }
+        }
+    }
+}
+
+int orc_detect_embed_mode(const orc_ctx* c, const uint8_t* frames, int n, int H, int W, const orc_params* P, int mode,
+                          float* box_out, float* prob_out, int32_t* rect_out, uint8_t* valid_out, float* emb_out) {
+    if (mode == 0) return orc_detect_embed(c, frames, n, H, W, P, box_out, prob_out, rect_out, valid_out, emb_out, NULL);
+    const int S = 160;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; i++) {
+        const uint8_t* fr = frames + (size_t)i * H * W * 3;
+        float bx[4 * 64], pr[64];
+        int k = orc_detect(c, fr, H, W, P, bx, pr, 64, NULL);
+        memset(box_out + 4 * i, 0, 16); memset(rect_out + 4 * i, 0, 16);
+        prob_out[i] = 0.f; valid_out[i] = 0;
+        memset(emb_out + (size_t)i * 512, 0, 2048);
+        if (k <= 0) continue;
+        memcpy(box_out + 4 * i, bx, 16);
+        prob_out[i] = pr[0];
+        long b0 = (long)bx[0], b1 = (long)bx[1], b2 = (long)bx[2], b3 = (long)bx[3];   /* extract_face, margin 0 */
+        if (b0 < 0) b0 = 0;
+        if (b1 < 0) b1 = 0;
+        if (b2 > W) b2 = W;
+        if (b3 > H) b3 = H;
+        rect_out[4 * i] = (int32_t)b0; rect_out[4 * i + 1] = (int32_t)b1; rect_out[4 * i + 2] = (int32_t)b2; rect_out[4 * i + 3] = (int32_t)b3;
+        if (!(b2 > b0 && b3 > b1)) continue;
+        float* face = (float*)malloc((size_t)S * S * 3 * sizeof(float));
+        orc_crop_area_std(fr, H, W, (int)b0, (int)b1, (int)b2, (int)b3, S, mode == 2, face);
+        orc_facenet(c, face, 1, S, S, emb_out + (size_t)i * 512);
+        free(face);
+        valid_out[i] = 1;
+    }
+    return 0;
+}
+
 int orc_detect_embed(const orc_ctx* c, const uint8_t* frames, int n, int H, int W, const orc_params* P,
                      float* box_out, float* prob_out, int32_t* rect_out, uint8_t* valid_out,
                      float* emb_out, uint8_t* face_out) {

@@ -107,6 +107,12 @@ int   orc_detect_embed(const orc_ctx*, const uint8_t* frames, int n, int H, int 
 int   orc_drift_score(const float* emb, const uint8_t* valid, int n, long frame_count, int fps,
                       float* sims_out, uint8_t* flag_out, int* final_run, int* hits);
 
+/* mode 0 = reference (80x80 INTER_LINEAR, BGR, /255); 1 = facenet-pytorch extract_face for tensor
+ * input (160x160 area resample, .byte(), (x-127.5)/128), BGR kept; 2 = the same with BGR->RGB. */
+void  orc_crop_area_std(const uint8_t* img, int H, int W, int x0, int y0, int x1, int y1, int S, int rgb, float* out);
+int   orc_detect_embed_mode(const orc_ctx*, const uint8_t* frames, int n, int H, int W, const orc_params*, int mode,
+                            float* box_out, float* prob_out, int32_t* rect_out, uint8_t* valid_out, float* emb_out);
+
 /* one NV12 frame (H*W luma + H/2 x W interleaved UV) -> BGR, OpenCV integer BT.601 */
 void  orc_nv12_to_bgr(const uint8_t* nv12, int H, int W, uint8_t* bgr);
 

@@ -121,3 +121,21 @@ def test_nv12_ingest_with_sampling(engine, oracle):
         assert np.array_equal(out[j], oracle.nv12_to_bgr(nv12[i], H, W)), i
     with pytest.raises(Exception):
         engine.ingest_nv12(nv12[:, :-3], H, W, step)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_native_embedding_mode(blob, oracle, mode):
+    """SURVEY 8(f)-4: 160x160 area-resampled, standardised (optionally RGB) crops behind a flag;
+    the default (mode 0) stays the reference's 80x80 BGR /255 path."""
+    from truely_amd.engine import Engine
+    eng = Engine(blob, embed_mode=mode)
+    fr = truely_amd.synthetic.synthetic_frames(3, 360, 640, seed=11)
+    out = eng.detect_embed(fr)
+    ref = oracle.detect_embed_mode(fr, mode)
+    assert ref["valid"].sum() >= 1
+    assert np.array_equal(out["valid"].cpu().numpy(), ref["valid"]) and np.array_equal(out["rect"].cpu().numpy(), ref["rect"])
+    emb = out["emb"].cpu().numpy()
+    assert np.abs(emb - ref["emb"]).max() <= 1e-4
+    assert np.array_equal(emb, ref["emb"])
+    base = oracle.detect_embed(fr)["emb"]
+    assert not np.array_equal(base, ref["emb"])        # a different crop pipeline, not the parity default

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libtruely_hip.so")
 class TrlConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("min_face_size", C.c_int), ("thr0", C.c_float), ("thr1", C.c_float),
                 ("thr2", C.c_float), ("factor", C.c_double), ("cap_level", C.c_int), ("cap_frame", C.c_int),
-                ("max_faces", C.c_int), ("pnet_mode", C.c_int)]
+                ("max_faces", C.c_int), ("pnet_mode", C.c_int), ("embed_mode", C.c_int)]
 
 
 class TrlError(RuntimeError):
@@ -66,7 +66,7 @@ def load(path: str | None = None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.trl_abi_version() != 1:
+    if lib.trl_abi_version() != 2:
         raise ImportError("libtruely_hip ABI mismatch")
     _lib = lib
     return lib

@@ -29,13 +29,14 @@ int trl_default_config(trl_config* cfg) {
     cfg->cap_frame = 2048;
     cfg->max_faces = 64;
     cfg->pnet_mode = 0;
+    cfg->embed_mode = 0;
     return TRL_OK;
 }
 
 int trl_create(const trl_config* cfg, trl_ctx** out) {
     if (!cfg || !out) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
     if (cfg->cap_level < 64 || cfg->cap_level > 3072 || cfg->cap_frame < 64 || cfg->cap_frame > 3072 || (cfg->cap_level & 3) ||
-        (cfg->cap_frame & 3) || cfg->min_face_size < 12 || cfg->max_faces < 1 || !(cfg->factor > 0.1 && cfg->factor < 0.99)) {
+        (cfg->cap_frame & 3) || cfg->min_face_size < 12 || cfg->max_faces < 1 || !(cfg->factor > 0.1 && cfg->factor < 0.99) || cfg->embed_mode < 0 || cfg->embed_mode > 2) {
         trl_set_error("bad trl_config (capacities must be multiples of 4 in [64,3072], min_face_size >= 12)");
         return TRL_ERR_INVALID;
     }
@@ -312,12 +313,14 @@ int trl_detect_embed(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, f
     TRL_HIP(hipEventRecord(c->ev_call0, s));
     TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
     TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, s));
+    const int S = c->cfg.embed_mode == 0 ? 80 : 160;
     c->scratch.reset();
-    TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * (80 * 80 * 110 + 400000) * 4 + (8u << 20)));
-    float* faces = (float*)c->scratch.alloc((size_t)n * 80 * 80 * 3 * 4);
+    TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * ((size_t)S * S * 110 + 400000) * 4 + (8u << 20)));
+    float* faces = (float*)c->scratch.alloc((size_t)n * S * S * 3 * 4);
     if (!faces) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
-    TRL_CHECK(trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, faces, s));
-    TRL_CHECK(trl_run_facenet(c, faces, n, 80, 80, d_valid, d_emb, s));
+    if (c->cfg.embed_mode == 0) TRL_CHECK(trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, faces, s));
+    else TRL_CHECK(trl_launch_crop_area_std(d_frames, n, H, W, d_rect, d_valid, S, c->cfg.embed_mode == 2, faces, s));
+    TRL_CHECK(trl_run_facenet(c, faces, n, S, S, d_valid, d_emb, s));
     TRL_HIP(hipEventRecord(c->ev_call1, s));
     TRL_HIP(hipStreamSynchronize(s));
     collect_timings(c);

@@ -552,6 +552,33 @@ __global__ __launch_bounds__(256) void k_crop_resize80(const uint8_t* __restrict
     }
 }
 
+// SURVEY 8(f)-4 native embedding mode: facenet-pytorch extract_face() for tensor input = crop -> imresample (area)
+// to SxS -> .byte() (truncation) -> fixed_image_standardization (x-127.5)/128, optionally BGR -> RGB.
+__global__ __launch_bounds__(256) void k_crop_area_std(const uint8_t* __restrict__ frames, int H, int W, const int32_t* __restrict__ rect,
+                                                       const uint8_t* __restrict__ valid, int S, int rgb, float* __restrict__ out) {
+    const int f = blockIdx.y;
+    float* o = out + (size_t)f * S * S * 3;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= S * S) return;
+    if (!valid[f]) { o[3 * p] = 0.f; o[3 * p + 1] = 0.f; o[3 * p + 2] = 0.f; return; }
+    const int x0 = rect[4 * f], y0 = rect[4 * f + 1], iw = rect[4 * f + 2] - x0, ih = rect[4 * f + 3] - y0;
+    const int oy = p / S, ox = p - oy * S;
+    const int ys = (int)(((long long)oy * ih) / S), ye = (int)((((long long)oy + 1) * ih + S - 1) / S);
+    const int xs = (int)(((long long)ox * iw) / S), xe = (int)((((long long)ox + 1) * iw + S - 1) / S);
+    unsigned s0 = 0, s1 = 0, s2 = 0;
+    const uint8_t* fp = frames + (size_t)f * H * W * 3;
+    for (int y = ys; y < ye; y++) {
+        const uint8_t* q = fp + ((size_t)(y0 + y) * W + x0 + xs) * 3;
+        for (int x = xs; x < xe; x++, q += 3) { s0 += q[0]; s1 += q[1]; s2 += q[2]; }
+    }
+    const float kh = (float)(ye - ys), kw = (float)(xe - xs);
+    const float b0 = (float)(unsigned char)((float)s0 / kh / kw), b1 = (float)(unsigned char)((float)s1 / kh / kw),
+                b2 = (float)(unsigned char)((float)s2 / kh / kw);
+    o[3 * p + (rgb ? 2 : 0)] = (b0 - 127.5f) / 128.0f;
+    o[3 * p + 1] = (b1 - 127.5f) / 128.0f;
+    o[3 * p + (rgb ? 0 : 2)] = (b2 - 127.5f) / 128.0f;
+}
+
 template <typename K>
 int set_dyn_smem(K kernel, size_t bytes) {
     TRL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -598,6 +625,13 @@ int trl_launch_area_level(const uint8_t* d_frames, int nf, int H, int W, int h, 
 }
 int trl_launch_heads_to_maps(const float* d_heads, int cells, float* d_prob, float* d_reg, hipStream_t s) {
     k_heads_to_maps<<<(cells + 255) / 256, 256, 0, s>>>(d_heads, cells, d_prob, d_reg);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+int trl_launch_crop_area_std(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid, int S,
+                             bool rgb, float* d_faces, hipStream_t s) {
+    if (n <= 0) return TRL_OK;
+    k_crop_area_std<<<dim3((S * S + 255) / 256, n), 256, 0, s>>>(d_frames, H, W, d_rect, d_valid, S, rgb ? 1 : 0, d_faces);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }

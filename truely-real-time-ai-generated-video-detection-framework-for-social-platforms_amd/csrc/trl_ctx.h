@@ -74,6 +74,8 @@ int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
                        int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, hipStream_t s);
 int trl_launch_crop_resize80(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid,
                              float* d_faces, hipStream_t s);
+int trl_launch_crop_area_std(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid, int S,
+                             bool rgb, float* d_faces, hipStream_t s);
 int trl_launch_area_level(const uint8_t* d_frames, int nf, int H, int W, int h, int w, float* d_level, hipStream_t s);
 int trl_launch_heads_to_maps(const float* d_heads, int cells, float* d_prob, float* d_reg, hipStream_t s);
 int trl_compute_levels(trl_ctx* c, int H, int W);

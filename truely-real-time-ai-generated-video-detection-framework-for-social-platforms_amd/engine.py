@@ -24,7 +24,7 @@ def _ptr(t: Optional[torch.Tensor]):
 class Engine:
     def __init__(self, blob: bytes | None = None, device: int | None = None, pnet_mode: int | None = None,
                  cap_level: int | None = None, cap_frame: int | None = None, min_face_size: int = 20,
-                 thresholds=(0.6, 0.7, 0.7), factor: float = 0.709, max_faces: int = 64):
+                 thresholds=(0.6, 0.7, 0.7), factor: float = 0.709, max_faces: int = 64, embed_mode: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("truely_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _lib.load()
@@ -35,6 +35,7 @@ class Engine:
         cfg.thr0, cfg.thr1, cfg.thr2 = (float(t) for t in thresholds)
         cfg.factor = float(factor)
         cfg.max_faces = int(max_faces)
+        cfg.embed_mode = int(embed_mode)
         if pnet_mode is not None:
             cfg.pnet_mode = int(pnet_mode)
         if cap_level:
