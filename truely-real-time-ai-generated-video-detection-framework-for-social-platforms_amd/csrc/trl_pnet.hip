@@ -258,15 +258,14 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
     __shared__ float HSall[4 * 32 * 9];                           // per-wave head outputs [32 cells][9]
+    __shared__ __attribute__((aligned(16))) float B3S[144 * 32]; // conv3 weights [k][cout]: read per k-chain batch, not held in VGPRs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;      // 16x16x4 operand coordinates
     const int l31 = lane & 31, hh = lane >> 5;      // 32x32x2 operand coordinates
 
     // ---- B operands: every weight matrix stays in registers for the whole launch -----------------------------
-    float B3[72];
-#pragma unroll
-    for (int s = 0; s < 72; s++) B3[s] = a.w3[(2 * s + hh) * 32 + l31];
+    for (int i = tid; i < 144 * 32; i += 256) B3S[i] = a.w3[i];          // conv3 B operand [k][32] in LDS (18 KB)
     float B1[7], B2[23], BH[8];
 #pragma unroll
     for (int s = 0; s < 7; s++) B1[s] = a.w1[(4 * s + kq) * 32 + l15];
@@ -470,16 +469,17 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[q] = bias3;
 #pragma unroll
-                for (int half = 0; half < 3; half++) {      // 3 x 24 k-steps: the operands of a third are all in flight first
-                    float xa[24];
+                for (int half = 0; half < 3; half++) {      // 3 x 24 k-steps: both operands of a third are in flight first
+                    float xa[24], wb[24];
 #pragma unroll
                     for (int u = 0; u < 24; u++) {
                         const int s = half * 24 + u, tap = s >> 3, ky = tap / 3, kx = tap - ky * 3;
                         xa[u] = RA[base + (ky * C2_T + kx) * C2_LD + 2 * (s & 7)];
+                        wb[u] = B3S[(2 * s + hh) * 32 + l31];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < 24; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u], B3[half * 24 + u], acc, 0, 0, 0);
+                    for (int u = 0; u < 24; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u], wb[u], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
