@@ -13,6 +13,11 @@ import truely_amd  # noqa: E402  (import shim for the hyphenated package directo
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once, loudly
+    from truely_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libtrl_oracle.so")):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")

@@ -45,25 +45,25 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
     c->cfg = *cfg;
     if (hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess) { delete c; trl_set_error("hipHostMalloc failed"); return TRL_ERR_HIP; }
     memset(c->h_pinned, 0, 256);
-    hipEventCreate(&c->ev_call0);
-    hipEventCreate(&c->ev_call1);
+    (void)hipEventCreate(&c->ev_call0);
+    (void)hipEventCreate(&c->ev_call1);
     *out = c;
     return TRL_OK;
 }
 
 int trl_destroy(trl_ctx* c) {
     if (!c) return TRL_OK;
-    hipSetDevice(c->cfg.device);
-    hipDeviceSynchronize();
-    if (c->wdev) hipFree(c->wdev);
-    if (c->arena.base) hipFree(c->arena.base);
-    if (c->scratch.base) hipFree(c->scratch.base);
-    if (c->sims_tmp.base) hipFree(c->sims_tmp.base);
-    if (c->pyr_tab) hipFree(c->pyr_tab);
-    if (c->h_pinned) hipHostFree(c->h_pinned);
-    if (c->ev_call0) hipEventDestroy(c->ev_call0);
-    if (c->ev_call1) hipEventDestroy(c->ev_call1);
-    for (auto& e : c->pnet_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (c->wdev) (void)hipFree(c->wdev);
+    if (c->arena.base) (void)hipFree(c->arena.base);
+    if (c->scratch.base) (void)hipFree(c->scratch.base);
+    if (c->sims_tmp.base) (void)hipFree(c->sims_tmp.base);
+    if (c->pyr_tab) (void)hipFree(c->pyr_tab);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);
+    if (c->ev_call1) (void)hipEventDestroy(c->ev_call1);
+    for (auto& e : c->pnet_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c;
     return TRL_OK;
 }
@@ -256,12 +256,12 @@ static int check_call(trl_ctx* c, const void* frames, int n, int H, int W) {
 
 static void collect_timings(trl_ctx* c) {
     float call_ms = 0.f, pnet_ms = 0.f, pyr_ms = 0.f;
-    hipEventElapsedTime(&call_ms, c->ev_call0, c->ev_call1);
+    (void)hipEventElapsedTime(&call_ms, c->ev_call0, c->ev_call1);
     int launches = 0;
     if (c->cfg.pnet_mode == 0 && c->pnet_ev_used >= 2) {
         // pair 0 = pyramid kernel, pair 1 = the fused PNet kernel (the dominant kernel, one launch)
-        hipEventElapsedTime(&pyr_ms, c->pnet_ev[0].first, c->pnet_ev[0].second);
-        hipEventElapsedTime(&pnet_ms, c->pnet_ev[1].first, c->pnet_ev[1].second);
+        (void)hipEventElapsedTime(&pyr_ms, c->pnet_ev[0].first, c->pnet_ev[0].second);
+        (void)hipEventElapsedTime(&pnet_ms, c->pnet_ev[1].first, c->pnet_ev[1].second);
         launches = 1;
     } else {
         for (int i = 0; i < c->pnet_ev_used; i++) {

@@ -420,28 +420,37 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         if (!(a.dbg_skip & 4)) {
             // 21 M-tiles of 16 rows (last one 4 rows); wave w takes pairs (w, w+4), (w+8, w+12), (w+16, w+20).
             // RA (the input tile) is dead since the barrier above, so the epilogue may overwrite it.
-#pragma unroll 1
-            for (int j = 0; j < 3; j++) {
-                const int mtA = wave + 8 * j, mtB = mtA + 4;
-                const bool hasB = mtB < 21;
+            // The A operands of pair j+1 are requested right after the MFMAs of pair j are issued, so their LDS
+            // latency hides under that pair's tail and epilogue (same registers: MFMA sources are read at issue).
+            float xa[23], xb[23];
+            auto read_pair2 = [&](int j) {
+                const int mtA = wave + 8 * j, mtB = (mtA + 4 < 21) ? mtA + 4 : mtA;
                 int mA = mtA * 16 + l15; mA = mA < 324 ? mA : 323;
-                int mB = (hasB ? mtB : mtA) * 16 + l15; mB = mB < 324 ? mB : 323;
+                int mB = mtB * 16 + l15; mB = mB < 324 ? mB : 323;
                 const int yA = mA / C2_T, xA = mA - yA * C2_T, yB = mB / C2_T, xB = mB - yB * C2_T;
                 const int baseA = (yA * P1_T + xA) * 10, baseB = (yB * P1_T + xB) * 10;
-                f32x4 accA = {bias2, bias2, bias2, bias2}, accB = accA;
-                float xa[23], xb[23];
 #pragma unroll
                 for (int s = 0; s < 23; s++) {
                     const int ko = koff<30, 170>(s, kq, 0, e2_2, 0);
                     xa[s] = RB[baseA + ko];
                     xb[s] = RB[baseB + ko];
                 }
+            };
+            read_pair2(0);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int mtA = wave + 8 * j, mtB = mtA + 4;
+                const bool hasB = mtB < 21;
+                f32x4 accA = {bias2, bias2, bias2, bias2}, accB = accA;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 23; s++) {
                     accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
                     accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B2[s], accB, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j < 2) read_pair2(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int ra = mtA * 16 + kq * 4 + q;
