@@ -167,12 +167,21 @@ static void conv2d(const T* x, const float* w, const float* bias, int KH, int KW
                    float* y, int ldy, int coff, int OH, int OW) {
     const int Cin = x->c, H = x->h, W = x->w;
     const long rows = (long)x->n * OH;
+    /* Long reductions over tiny maps (OH*OW <= 9, K >= 512: the 3x3 / 1x1-spatial tail of FaceNet and the
+     * dense layers of R/O-Net) are accumulated as FOUR chains over consecutive quarters of k, combined as
+     * (c0 + c1) + (c2 + c3); chain 0 starts at the bias.  The rule depends on the layer only, never on the
+     * batch, and is what lets the GPU give each quarter to its own wave (see conv_splitk4 in trl_layers.hip). */
+    const int Ktot = KH * KW * Cin;
+    const int nseg = (OH * OW <= 9 && Ktot >= 512 && (Ktot & 15) == 0) ? 4 : 1;
+    const int segK = Ktot / nseg;
 #pragma omp parallel for schedule(static) if (rows * OW * Cout * KH * KW * Cin > 2000000L)
     for (long row = 0; row < rows; row++) {
         int n = (int)(row / OH), oy = (int)(row % OH);
-        float acc[2048];
+        float accs[4][2048];
+        float* acc = accs[0];
         for (int ox = 0; ox < OW; ox++) {
-            for (int co = 0; co < Cout; co++) acc[co] = bias ? bias[co] : 0.f;
+            for (int sg = 0; sg < nseg; sg++)
+                for (int co = 0; co < Cout; co++) accs[sg][co] = (sg == 0 && bias) ? bias[co] : 0.f;
             for (int ky = 0; ky < KH; ky++) {
                 int iy = oy * sh - ph + ky;
                 if (iy < 0 || iy >= H) continue;
@@ -184,10 +193,13 @@ static void conv2d(const T* x, const float* w, const float* bias, int KH, int KW
                     for (int c = 0; c < Cin; c++) {
                         const float a = xp[c];
                         const float* wr = wp + (size_t)c * Cout;
-                        for (int co = 0; co < Cout; co++) acc[co] = fmaf(a, wr[co], acc[co]);
+                        float* ac = accs[nseg == 1 ? 0 : ((ky * KW + kx) * Cin + c) / segK];
+                        for (int co = 0; co < Cout; co++) ac[co] = fmaf(a, wr[co], ac[co]);
                     }
                 }
             }
+            if (nseg == 4)
+                for (int co = 0; co < Cout; co++) acc[co] = (accs[0][co] + accs[1][co]) + (accs[2][co] + accs[3][co]);
             size_t pix = ((size_t)n * OH + oy) * OW + ox;
             float* yp = y + pix * ldy + coff;
             for (int co = 0; co < Cout; co++) {

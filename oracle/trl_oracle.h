@@ -21,6 +21,8 @@
  *     chain per output element:  acc = bias (or 0);  for k ascending:
  *     acc = fmaf(x[k], w[k], acc),  k = (ky*KW + kx)*Cin + c   (NHWC, HWIO).
  *     gfx950's v_mfma_f32_32x32x2_f32 / 16x16x4_f32 compute exactly this chain.
+ *     Exception (layer rule, batch independent): when OH*OW <= 9 and K >= 512 the chain is cut into four
+ *     consecutive quarters of k, combined as (c0 + c1) + (c2 + c3), c0 seeded with the bias.
  *   - elementwise steps mirror the torch / numpy expression order, one IEEE
  *     rounding per operation, no contraction (-ffp-contract=off on both sides).
  *   - exp() is a fixed fmaf polynomial (orc_expf) shared verbatim with the device code.

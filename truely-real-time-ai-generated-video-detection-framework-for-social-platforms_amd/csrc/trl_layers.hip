@@ -197,6 +197,129 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
     }
 }
 
+// ---- split-K(4) variant --------------------------------------------------------------------------------
+// Tiny maps with long reductions (OH*OW <= 9, K >= 512: FaceNet's 3x3 / 1x1-spatial tail, the R/O-Net dense
+// layers) have few output tiles and a serial chain of K/2 dependent 64-cycle MFMAs each.  The oracle defines
+// their accumulation as four chains over consecutive quarters of k combined as (c0+c1)+(c2+c3); here wave w of
+// a workgroup owns quarter w of one 32x64 output tile: staging is wave-private (no workgroup barrier in the K
+// loop), the four SIMDs of the CU work on the same tile, and the chain per wave is four times shorter.
+__global__ __launch_bounds__(256) void conv_splitk4(ConvArgs a) {
+    constexpr int BM = 32, BN = 64, BK = 32;
+    __shared__ __attribute__((aligned(16))) float As[4][BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[4][BK * BN];     // later: the 4 x (32x64) partial tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int segK = a.K >> 2, ks = wave * segK, ke = ks + segK;
+
+    const int m = m0 + r;
+    const bool mvalid = m < a.M;
+    const int mm = mvalid ? m : 0;
+    const int ohw = a.OH * a.OW;
+    const int nimg = mm / ohw;
+    const int rem = mm - nimg * ohw;
+    const int oy = rem / a.OW, ox = rem - oy * a.OW;
+    const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
+    const float* xbase = a.x + (size_t)nimg * a.H * a.W * a.ldx + a.xoff;
+
+    // A: 32 rows x 8 float4 groups per chunk = 4 slots per lane (same row, groups h, h+2, h+4, h+6)
+    int cur_c[4], cur_kx[4], cur_ky[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int k = ks + 4 * (h + 2 * i);
+        const int tap = k / a.Cin;
+        cur_c[i] = k - tap * a.Cin;
+        cur_ky[i] = tap / a.KW;
+        cur_kx[i] = tap - cur_ky[i] * a.KW;
+    }
+    float4 areg[4], breg[8];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = k0 + 4 * (h + 2 * i);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mvalid && k < ke) {
+                const int iy = iy0 + cur_ky[i], ix = ix0 + cur_kx[i];
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    v = *reinterpret_cast<const float4*>(xbase + ((size_t)iy * a.W + ix) * a.ldx + cur_c[i]);
+            }
+            areg[i] = v;
+            cur_c[i] += BK;
+            while (cur_c[i] >= a.Cin) {
+                cur_c[i] -= a.Cin;
+                if (++cur_kx[i] == a.KW) { cur_kx[i] = 0; ++cur_ky[i]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int slot = lane + 64 * i;
+            const int kk = slot >> 4, n = n0 + 4 * (slot & 15);
+            breg[i] = (k0 + kk < ke && n < a.ldw) ? *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + kk) * a.ldw + n)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float* Aw = As[wave];
+    float* Bw = Bs[wave];
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int g = h + 2 * i;
+            Aw[(4 * g + 0) * BM + r] = areg[i].x; Aw[(4 * g + 1) * BM + r] = areg[i].y;
+            Aw[(4 * g + 2) * BM + r] = areg[i].z; Aw[(4 * g + 3) * BM + r] = areg[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int slot = lane + 64 * i;
+            *reinterpret_cast<float4*>(&Bw[(slot >> 4) * BN + 4 * (slot & 15)]) = breg[i];
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        const int n = n0 + tn * 32 + r;
+        const float b = (wave == 0 && a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;   // chain 0 starts at the bias
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[tn][i] = b;
+    }
+    load_chunk(ks);
+    for (int k0 = ks; k0 < ke; k0 += BK) {
+        store_chunk();                                   // wave-private staging: LDS ops of one wave stay in order
+        if (k0 + BK < ke) load_chunk(k0 + BK);
+#pragma unroll
+        for (int s = 0; s < BK / 2; s++) {
+            const float av = Aw[(2 * s + h) * BM + r];
+            const float b0 = Bw[(2 * s + h) * BN + r], b1 = Bw[(2 * s + h) * BN + 32 + r];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* red = &Bs[0][0];                              // [wave][tn][reg][lane]
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) red[((wave * 2 + tn) * 16 + i) * 64 + lane] = acc[tn][i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int e = tid + 256 * j;
+        const int tn = e >> 10, reg = (e >> 6) & 15, ln = e & 63;
+        const int mr = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
+        const int n = n0 + tn * 32 + (ln & 31);
+        if (mr >= a.M || n >= a.Cout) continue;
+        float v = (red[e] + red[2048 + e]) + (red[4096 + e] + red[6144 + e]);
+        if (a.scale) v = __builtin_fmaf(v, a.scale[n], a.shift[n]);
+        if (a.res) {
+            v = v * a.res_scale;
+            v = v + a.res[(size_t)mr * a.ldres + n];
+        }
+        if (a.act == TRL_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (a.act == TRL_ACT_PRELU) v = v > 0.f ? v : a.slope[n] * v;
+        a.y[(size_t)mr * a.ldy + a.yoff + n] = v;
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 int launch_cfg(const ConvArgs& a, bool vec, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
@@ -347,6 +470,14 @@ __global__ __launch_bounds__(256) void drift_scan_kernel(const float* __restrict
 int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
     if (a.M <= 0) return TRL_OK;
     const bool vec = (a.Cin % 4 == 0) && (a.ldx % 4 == 0) && (a.xoff % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
+    // The oracle's four-chain rule for tiny maps with long reductions (oracle/trl_oracle.c conv2d)
+    if (a.OH * a.OW <= 9 && a.K >= 512 && (a.K & 15) == 0) {
+        if (!vec) { trl_set_error("split-K layer needs Cin %% 4 == 0 and 16-byte aligned input"); return TRL_ERR_INVALID; }
+        dim3 grid((a.M + 31) / 32, (a.Cout + 63) / 64);
+        conv_splitk4<<<grid, 256, 0, s>>>(a);
+        TRL_LAUNCH_CHECK();
+        return TRL_OK;
+    }
     // Deep K chunks (BK = 64) when K is long: a chunk's MFMAs (BK/2 x 64 cycles per wave tile) must cover
     // the global-load round trip of the next chunk, the only latency hiding a lone workgroup per CU has.
     const bool deep = a.K >= 192;
