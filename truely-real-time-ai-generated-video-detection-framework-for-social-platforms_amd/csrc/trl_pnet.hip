@@ -105,7 +105,7 @@ __device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF
     return (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
 }
 
-struct PyrArgs { int H, W, n_frames; long long pyr_stride; PLevel g; };
+struct PyrArgs { int H, W, n_frames, f0; long long pyr_stride; PLevel g; };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ frames, PyrArgs a, const uint32_t* __restrict__ tab,
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ fra
     const PLevel& g = a.g;                                  // one launch per level: every field is a kernel argument (SGPRs)
     const int per_frame = g.pix_pad << g.gshift;            // threads of this level per frame
     constexpr int mode = MODE;
-    const int f = blockIdx.y;
+    const int f = a.f0 + blockIdx.y;
     const uint32_t* base32 = reinterpret_cast<const uint32_t*>(frames);
     const long long fbase = (long long)f * a.H * a.W * 3;
     const long long last_dw = ((long long)a.n_frames * a.H * a.W * 3 - 1) >> 2;
@@ -649,15 +649,24 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     if (!pyr) { trl_set_error("pyramid workspace"); return TRL_ERR_STATE; }
     a.pyr = pyr;
     if (ev) TRL_HIP(hipEventRecord(ev[0], s));
-    for (int l = 0; l < a.L; l++) {
-        PyrArgs pa;
-        pa.H = H; pa.W = W; pa.n_frames = n; pa.pyr_stride = a.pyr_stride; pa.g = a.lv[l];
-        const int threads = pa.g.pix_pad << pa.g.gshift;
-        dim3 grid((threads + 255) / 256, n);
-        if (pa.g.mode == 0) k_pyramid<0><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
-        else if (pa.g.mode == 1) k_pyramid<1><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
-        else k_pyramid<2><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
-        TRL_LAUNCH_CHECK();
+    // Frames are resampled in chunks whose source bytes fit the 256 MiB Infinity Cache: every level re-reads the
+    // whole source image, so the 2nd..11th level launches of a chunk are served on-die instead of from HBM.
+    static const int chunk_env = getenv("TRL_PYR_CHUNK") ? atoi(getenv("TRL_PYR_CHUNK")) : 0;
+    int chunk = chunk_env > 0 ? chunk_env : (int)((176ll << 20) / ((long long)H * W * 3));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    for (int f0 = 0; f0 < n; f0 += chunk) {
+        const int nf = (n - f0 < chunk) ? n - f0 : chunk;
+        for (int l = 0; l < a.L; l++) {
+            PyrArgs pa;
+            pa.H = H; pa.W = W; pa.n_frames = n; pa.f0 = f0; pa.pyr_stride = a.pyr_stride; pa.g = a.lv[l];
+            const int threads = pa.g.pix_pad << pa.g.gshift;
+            dim3 grid((threads + 255) / 256, nf);
+            if (pa.g.mode == 0) k_pyramid<0><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+            else if (pa.g.mode == 1) k_pyramid<1><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+            else k_pyramid<2><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+            TRL_LAUNCH_CHECK();
+        }
     }
     if (ev) { TRL_HIP(hipEventRecord(ev[1], s)); TRL_HIP(hipEventRecord(ev[2], s)); }
     const int total_tiles = a.tiles_per_frame * n;
