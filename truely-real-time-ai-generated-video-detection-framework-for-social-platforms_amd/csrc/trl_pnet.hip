@@ -22,6 +22,7 @@
 //                 neighbouring tiles hit the same L2).
 #include "trl_ctx.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -38,7 +39,7 @@ constexpr int C2_LD = 17;         // padded channel stride of the conv2 tile (ba
 constexpr int ST_LD = 33;         // padded channel stride of the per-wave conv3 staging tile
 constexpr int REGION_A = C2_T * C2_T * C2_LD;        // 5508 floats: input tile, later conv2 output
 constexpr int REGION_B = 4 * 32 * ST_LD;             // 4224 floats: pooled conv1, later conv3 staging
-static_assert(IN_T * IN_T * 3 <= REGION_A, "input tile fits region A");
+static_assert(3 * 7 * 256 <= REGION_A, "input tile (+ the 28 overhang pixels of the 7x256 copy) fits region A");
 static_assert(P1_T * P1_T * 10 <= REGION_B, "pooled tile fits region B");
 
 struct PLevel {
@@ -50,18 +51,20 @@ struct PLevel {
     int ytab0, xtab0;        // offsets of the level's row / column bin-edge tables
     int mode, nd, grshift;   // pyramid kernel path, re-aligned dwords per row (mode 0), log2 groups per row (mode 1)
     unsigned wmagic;         // ceil(2^32 / w): pixel / w by __umulhi
+    unsigned txmagic;        // ceil(2^32 / tiles_x): tile decode stays on the scalar unit
     float scale;
 };
 struct PnetArgs {
     const float4* pyr; long long pyr_stride;   // float4 per frame
     int n_frames, L, tiles_per_frame, H, W;
+    unsigned tpf_magic;                        // ceil(2^32 / tiles_per_frame)
     long long work_per_frame;                  // pyramid kernel threads per frame
     PLevel lv[16];
     const float *w1, *w2, *w3, *wh;            // [Kpad][32] zero padded
     const float *b1, *b2, *b3, *bh, *s1, *s2, *s3;
     float thr; int cap;
     int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); 0 in production
-    int mono1;                                 // all conv1 PReLU slopes >= 0 (pool/PReLU may be swapped)
+    int mono1;                                 // 1: all conv1 PReLU slopes >= 0 (pool/PReLU may be swapped); 2: all in [0,1]
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
 };
 
@@ -260,7 +263,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ float HSall[4 * 32 * 9];                           // per-wave head outputs [32 cells][9]
     __shared__ __attribute__((aligned(16))) float B3S[144 * 32]; // conv3 weights [k][cout]: read per k-chain batch, not held in VGPRs
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every M-tile index below is SALU work
     const int l15 = lane & 15, kq = lane >> 4;      // 16x16x4 operand coordinates
     const int l31 = lane & 31, hh = lane >> 5;      // 32x32x2 operand coordinates
 
@@ -285,7 +289,11 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 
     // conv1 rows: i = pool cell (i>>2) x sub-position (i&3) of a 4-cell group
     const int c1_pc = l15 >> 2, c1_dy = (l15 >> 1) & 1, c1_dx = l15 & 1;
-    const int e1_1 = kq >= 1 ? 117 : 0, e1_2 = kq >= 2 ? 117 : 0, e1_3 = kq >= 3 ? 117 : 0;   // conv1: D = 9,  E = 126-9
+    // conv1 A-operand lane bases (k = 4s+kq walks a [42][3]-strided 3x3x3 patch: row step 126-9 = 117 floats once
+    // 4s+kq passes a multiple of 9) and the pooled-cell store base; everything else is an immediate offset.
+    const int c1_la0 = ((2 * wave + c1_dy) * IN_T + 2 * c1_pc + c1_dx) * 3 + kq;
+    const int c1_la1 = c1_la0 + (kq >= 1 ? 117 : 0), c1_la2 = c1_la0 + (kq >= 2 ? 117 : 0), c1_la3 = c1_la0 + (kq >= 3 ? 117 : 0);
+    const int c1_lp = (wave * P1_T + kq) * 10 + l15;
     const int e2_2 = kq >= 2 ? 170 : 0;                                                      // conv2: D = 30, E = 200-30
 
     const int total_tiles = a.tiles_per_frame * a.n_frames;
@@ -294,125 +302,145 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     const int chunk = (total_tiles + 7) / 8;
     const int t_begin = xcd * chunk, t_end = (t_begin + chunk < total_tiles) ? t_begin + chunk : total_tiles;
 
-    // tile -> (frame, level, ty, tx).  The per-level first-tile table is read once (it stays in scalar
-    // registers); the level is a branch-free count, not a dependent chain of kernarg loads per tile.
+    // tile -> (frame, level, ty, tx), all on the scalar unit: divisions are multiply-high by host magic numbers
+    // (an integer division would expand into a VALU float-reciprocal sequence, paid in MFMA issue slots), the
+    // level is a branch-free count over a first-tile table held in SGPRs.
     int lvl_t0[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) lvl_t0[i] = i < a.L ? a.lv[i].tile0 : 0x7fffffff;
-    auto decode = [&](int tile, int& f, int& l, int& ty, int& tx) {
-        f = tile / a.tiles_per_frame;
-        const int tt = tile - f * a.tiles_per_frame;
-        l = 0;
+    auto sdiv = [](int n, unsigned magic, int d) {
+        if (d == 1) return n;
+        int q = (int)__umulhi((unsigned)n, magic);
+        if (q * d > n) q--;
+        if (n - q * d >= d) q++;
+        return q;
+    };
+    struct TileId { int f, l, ty, tx; };
+    auto decode = [&](int tile) {
+        TileId t;
+        t.f = sdiv(tile, a.tpf_magic, a.tiles_per_frame);
+        const int tt = tile - t.f * a.tiles_per_frame;
+        t.l = 0;
 #pragma unroll
-        for (int i = 1; i < 16; i++) l += (tt >= lvl_t0[i]) ? 1 : 0;
-        const int tq = tt - a.lv[l].tile0;
-        ty = tq / a.lv[l].tiles_x;
-        tx = tq - ty * a.lv[l].tiles_x;
+        for (int i = 1; i < 16; i++) t.l += (tt >= lvl_t0[i]) ? 1 : 0;
+        const int tq = tt - a.lv[t.l].tile0;
+        t.ty = sdiv(tq, a.lv[t.l].txmagic, a.lv[t.l].tiles_x);
+        t.tx = tq - t.ty * a.lv[t.l].tiles_x;
+        return t;
     };
     // The next tile's 42x42 input pixels are fetched into registers while the current tile is in phase 3
     // (7 float4 per thread) and dropped into LDS at the top of the next iteration: the HBM/L2 latency of the
-    // only global read of the kernel is off the critical path.
+    // only global read of the kernel is off the critical path.  Thread t owns pixels p = t + 256 i; since
+    // 256 = 6*42 + 4, (iy, ix) of pixel i follow from (iy0, ix0) with one conditional wrap, and the address is
+    // a scalar tile base plus a 32-bit lane offset.  Interior tiles (the bulk) load without bounds tests.
+    const int pin_iy0 = tid / IN_T, pin_ix0 = tid - pin_iy0 * IN_T;
     float4 pre[7];
-    auto issue_input = [&](int tile) {
-        int f, l, ty, tx;
-        decode(tile, f, l, ty, tx);
-        const PLevel& g = a.lv[l];
-        const float4* src = a.pyr + (long long)f * a.pyr_stride + g.pix0;
-        const int gy0 = ty * 2 * TS, gx0 = tx * 2 * TS;
+    auto issue_input = [&](const TileId& t) {
+        const PLevel& g = a.lv[t.l];
+        const int gy0 = t.ty * 2 * TS, gx0 = t.tx * 2 * TS;
+        const char* srcb = reinterpret_cast<const char*>(a.pyr + (long long)t.f * a.pyr_stride + g.pix0 + (long long)gy0 * g.w + gx0);
+        const int w16 = g.w * 16;
+        const int hrem = g.h - gy0, wrem = g.w - gx0;
+        if (hrem >= IN_T && wrem >= IN_T) {
+            const unsigned v0 = (unsigned)(pin_iy0 * w16 + pin_ix0 * 16);
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const int p = tid + 256 * i;
-            const int iy = p / IN_T, ix = p - iy * IN_T;
-            const int gy = gy0 + iy, gx = gx0 + ix;
-            pre[i] = (p < IN_T * IN_T && gy < g.h && gx < g.w) ? src[(long long)gy * g.w + gx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 7; i++) {
+                unsigned vo = v0 + (unsigned)(i * (6 * w16 + 64)) + ((pin_ix0 >= IN_T - 4 * i) ? (unsigned)(w16 - IN_T * 16) : 0u);
+                if (i == 6) vo = (tid < IN_T * IN_T - 6 * 256) ? vo : 0u;     // p >= 42*42: reload pixel 0 (lands in the RA tail)
+                pre[i] = *reinterpret_cast<const float4*>(srcb + vo);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const bool wrap = pin_ix0 >= IN_T - 4 * i;
+                const int iy = pin_iy0 + 6 * i + (wrap ? 1 : 0), ix = pin_ix0 + 4 * i - (wrap ? IN_T : 0);
+                const bool ok = iy < hrem && ix < wrem && (i < 6 || tid < IN_T * IN_T - 6 * 256);
+                pre[i] = ok ? *reinterpret_cast<const float4*>(srcb + (unsigned)(iy * w16 + ix * 16)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
-
     float* const HS = HSall + wave * 32 * 9;
     int tile = t_begin + slot;
-    if (tile < t_end) issue_input(tile);
-    for (; tile < t_end; tile += per_xcd_blocks) {
-        int f, l, ty, tx;
-        decode(tile, f, l, ty, tx);
+    TileId cur = decode(tile < t_end ? tile : 0), nxt = cur;
+    if (tile < t_end) issue_input(cur);
+    for (; tile < t_end; tile += per_xcd_blocks, cur = nxt) {
+        const int f = cur.f, l = cur.l, ty = cur.ty, tx = cur.tx;
         const PLevel& g = a.lv[l];
 
         // ---- phase 0: prefetched input tile -> RA as [42][42][3] ---------------------------------------------
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const int p = tid + 256 * i;
-            if (p < IN_T * IN_T) { RA[3 * p + 0] = pre[i].x; RA[3 * p + 1] = pre[i].y; RA[3 * p + 2] = pre[i].z; }
+        for (int i = 0; i < 7; i++) {        // p < 1792: the 28 pixels past the tile land in RA's tail (finite, never a live operand)
+            float* d = RA + 3 * tid + 768 * i;
+            d[0] = pre[i].x; d[1] = pre[i].y; d[2] = pre[i].z;
         }
         __syncthreads();
 
         // ---- phase 1: conv1 + PReLU + 2x2 ceil max-pool -> RB as [20][20][10] ------------------------------
-        // 100 M-tiles (5 groups of 4 pool cells per pooled row), 25 per wave, processed as pairs of independent
-        // accumulator chains.  Software pipeline: the A operands of pair j+1 are read from LDS before the MFMAs of
-        // pair j are issued, and the (branch-free) pool epilogue of pair j runs in the shadow of those MFMAs.
+        // 100 M-tiles (5 groups of 4 pool cells per pooled row).  Wave w owns pooled rows w, w+4, .., w+16 (25
+        // M-tiles), so every LDS address is a per-wave lane base plus a COMPILE-TIME offset: the fully unrolled
+        // sequence spends no VALU on addressing (VALU and f32 MFMA share the FP32 pipe).  Tiles run as pairs of
+        // independent accumulator chains; the A operands of pair j+1 are read before the MFMAs of pair j issue
+        // and the pool epilogue of pair j-1 runs behind them.
         if (!(a.dbg_skip & 2)) {
             const int vy = g.h - 2 - ty * 2 * TS, vx = g.w - 2 - tx * 2 * TS;   // valid conv1 extent inside the tile
-            float xs0[14], xs1[14];
-            auto tile_base = [&](int mt) {
-                const int py = mt / 5, pg = mt - py * 5;
-                return ((2 * py + c1_dy) * IN_T + 2 * (4 * pg + c1_pc) + c1_dx) * 3;
-            };
-            auto read_pair = [&](int j, float (&x)[14]) {
-                const int mtA = wave + 8 * j, mtB = (mtA + 4 < 100) ? mtA + 4 : mtA;
-                const int baseA = tile_base(mtA), baseB = tile_base(mtB);
-#pragma unroll
-                for (int s = 0; s < 7; s++) {
-                    const int ko = koff<9, 117>(s, kq, e1_1, e1_2, e1_3);
-                    x[s] = RA[baseA + ko];
-                    x[7 + s] = RA[baseB + ko];
-                }
-            };
             // max-pool commutes with PReLU when the slope is >= 0 (monotone): pool first, one PReLU per cell.
             // Interior tiles (every conv1 pixel of the tile inside the level) also skip the ceil-mode masks.
             const bool fast = a.mono1 && vy >= 2 * P1_T && vx >= 2 * P1_T;
-            auto pool_store = [&](const f32x4& acc, int mt) {
-                const int py = mt / 5, px = 4 * (mt - py * 5) + kq;
-                float outv;
-                if (fast) {
-                    const float m01 = acc[0] > acc[1] ? acc[0] : acc[1], m23 = acc[2] > acc[3] ? acc[2] : acc[3];
-                    outv = prelu(m01 > m23 ? m01 : m23, slope1);
-                } else {
-                    const bool r0 = 2 * py < vy, r1 = 2 * py + 1 < vy, c0 = 2 * px < vx, c1 = 2 * px + 1 < vx;
-                    const float v0 = prelu(acc[0], slope1), v1 = prelu(acc[1], slope1), v2 = prelu(acc[2], slope1), v3 = prelu(acc[3], slope1);
-                    float m = v0;                                     // (dy,dx) = (0,0) is valid whenever the cell is
-                    m = (r0 && c1 && v1 > m) ? v1 : m;
-                    m = (r1 && c0 && v2 > m) ? v2 : m;
-                    m = (r1 && c1 && v3 > m) ? v3 : m;
-                    outv = (r0 && c0) ? m : 0.f;
-                }
-                if (l15 < 10) RB[(py * P1_T + px) * 10 + l15] = outv;
-            };
-            auto mma_pair = [&](const float (&x)[14], f32x4& accA, f32x4& accB) {
-                accA = f32x4{bias1, bias1, bias1, bias1};
-                accB = accA;
+            const bool unit = a.mono1 == 2;
+            auto conv1_pool = [&](auto FAST) {
+                constexpr bool kFast = decltype(FAST)::value;
+                float xs[2][14];
+                f32x4 acc[2][2];
+                auto read_tile = [&](int t, float* x) {             // t = 5*i + pg, compile time after unrolling
+                    const int off = (t / 5) * (8 * IN_T * 3) + (t % 5) * 24;
 #pragma unroll
-                for (int s = 0; s < 7; s++) {
-                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], B1[s], accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(x[7 + s], B1[s], accB, 0, 0, 0);
+                    for (int s = 0; s < 7; s++) {
+                        const int thr = 9 - (4 * s) % 9;            // koff<9,117>: which lane-dependent row step applies
+                        const int la = thr == 1 ? c1_la1 : (thr == 2 ? c1_la2 : (thr == 3 ? c1_la3 : c1_la0));
+                        x[s] = RA[la + off + 4 * s + 117 * ((4 * s) / 9)];
+                    }
+                };
+                auto pool_store = [&](const f32x4& v, int t) {
+                    const int i = t / 5, pg = t % 5;
+                    float outv;
+                    if (kFast) {
+                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        outv = unit ? fmaxf(m, slope1 * m) : prelu(m, slope1);
+                    } else {
+                        const int py = wave + 4 * i;
+                        const bool r0 = 2 * py < vy, r1 = 2 * py + 1 < vy;
+                        const bool c0 = 8 * pg + 2 * kq < vx, c1 = 8 * pg + 2 * kq + 1 < vx;
+                        const float v0 = prelu(v[0], slope1), v1 = prelu(v[1], slope1), v2 = prelu(v[2], slope1), v3 = prelu(v[3], slope1);
+                        float m = v0;                                 // (dy,dx) = (0,0) is valid whenever the cell is
+                        m = (r0 && c1 && v1 > m) ? v1 : m;
+                        m = (r1 && c0 && v2 > m) ? v2 : m;
+                        m = (r1 && c1 && v3 > m) ? v3 : m;
+                        outv = (r0 && c0) ? m : 0.f;
+                    }
+                    if (l15 < 10) RB[c1_lp + i * (4 * P1_T * 10) + pg * 40] = outv;
+                };
+                read_tile(0, xs[0]); read_tile(1, xs[0] + 7);
+#pragma unroll
+                for (int jp = 0; jp < 13; jp++) {
+                    const int cb = jp & 1;
+                    if (jp + 1 < 13) {
+                        read_tile(2 * jp + 2, xs[cb ^ 1]);
+                        if (2 * jp + 3 < 25) read_tile(2 * jp + 3, xs[cb ^ 1] + 7);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[cb][0] = f32x4{bias1, bias1, bias1, bias1};
+                    acc[cb][1] = acc[cb][0];
+#pragma unroll
+                    for (int s = 0; s < 7; s++) {
+                        acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][s], B1[s], acc[cb][0], 0, 0, 0);
+                        if (jp < 12) acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][7 + s], B1[s], acc[cb][1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (jp >= 1) { pool_store(acc[cb ^ 1][0], 2 * jp - 2); pool_store(acc[cb ^ 1][1], 2 * jp - 1); }
                 }
+                pool_store(acc[0][0], 24);
             };
-            read_pair(0, xs0);
-#pragma unroll 1
-            for (int jj = 0; jj < 6; jj++) {
-                f32x4 aA, aB, bA, bB;
-                read_pair(2 * jj + 1, xs1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_pair(xs0, aA, aB);
-                read_pair(2 * jj + 2, xs0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_pair(xs1, bA, bB);
-                const int mt0 = wave + 16 * jj;
-                pool_store(aA, mt0); pool_store(aB, mt0 + 4);
-                pool_store(bA, mt0 + 8); pool_store(bB, mt0 + 12);
-            }
-            {   // pair 12: M-tile wave+96 only (wave+100 does not exist)
-                f32x4 aA, aB;
-                mma_pair(xs0, aA, aB);
-                pool_store(aA, wave + 96);
-            }
+            if (fast) conv1_pool(std::true_type{}); else conv1_pool(std::false_type{});
         }
         __syncthreads();
 
@@ -463,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         __syncthreads();
 
         // next tile's input: global loads into registers only (RA is still read by phase 3)
-        if (tile + per_xcd_blocks < t_end) issue_input(tile + per_xcd_blocks);
+        if (tile + per_xcd_blocks < t_end) { nxt = decode(tile + per_xcd_blocks); issue_input(nxt); }
 
         // ---- phase 3: conv3 + PReLU -> per-wave staging -> heads -> candidates -------------------------------
         if (!(a.dbg_skip & 8)) {
@@ -559,8 +587,11 @@ int trl_pnet_prepare(trl_ctx* c) {
     }
     float sl[10];
     TRL_HIP(hipMemcpy(sl, trl_v(c, "pnet.prelu1")->p, sizeof sl, hipMemcpyDeviceToHost));
-    c->pnet_mono1 = 1;
-    for (float v : sl) if (!(v >= 0.f)) c->pnet_mono1 = 0;
+    c->pnet_mono1 = 2;
+    for (float v : sl) {
+        if (!(v <= 1.f) && c->pnet_mono1 == 2) c->pnet_mono1 = 1;
+        if (!(v >= 0.f)) c->pnet_mono1 = 0;
+    }
     return TRL_OK;
 }
 
@@ -574,6 +605,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
         PLevel& p = a.lv[l];
         p.h = g.h; p.w = g.w; p.oh = g.oh; p.ow = g.ow;
         p.tiles_x = (g.ow + TS - 1) / TS;
+        p.txmagic = (unsigned)((0x100000000ull + p.tiles_x - 1) / p.tiles_x);   // 2^32 for tiles_x == 1 wraps to 0: fixed up in sdiv()
         p.tile0 = tiles;
         tiles += p.tiles_x * ((g.oh + TS - 1) / TS);
         p.pix0 = (int)pix;
@@ -610,6 +642,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
         p.scale = (float)g.scale;
     }
     a.tiles_per_frame = tiles;
+    a.tpf_magic = (unsigned)((0x100000000ull + tiles - 1) / tiles);
     a.pyr_stride = pix;
     a.work_per_frame = work;
     a.w1 = trl_w(c, "pnet.conv1.w")->p; a.w2 = trl_w(c, "pnet.conv2.w")->p; a.w3 = trl_w(c, "pnet.conv3.w")->p; a.wh = trl_w(c, "pnet.heads.w")->p;
