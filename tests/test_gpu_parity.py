@@ -115,6 +115,31 @@ def test_cascade_fused_pnet_odd_sizes(engine, oracle):
         _check_cascade(engine, oracle, truely_amd.synthetic.synthetic_frames(3, H, W, seed=seed))
 
 
+@pytest.mark.parametrize("variant", ["slopes_above_one", "negative_slopes"])
+def test_cascade_fused_pnet_prelu_variants(variant):
+    """PReLU slopes outside [0, 1] take the generic kernel instantiation; a negative conv1 slope also forbids
+    the pool-before-PReLU shortcut.  Same bit-exact bar."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.oracle import Oracle
+    from truely_amd.engine import Engine
+    from truely_amd import weights
+    sds = [dict(sd) for sd in weights.synthetic_state_dicts(0)]
+    pnet = sds[0]
+    for key in ("prelu1.weight", "prelu2.weight", "prelu3.weight"):
+        w = np.array(pnet[key], np.float32, copy=True)
+        if variant == "slopes_above_one":
+            w[::2] = 1.25
+        else:
+            w[1::3] = -0.2
+        pnet[key] = w
+    blob = weights.pack_state_dicts(*sds)
+    eng, orc = Engine(blob), Oracle(blob)
+    _check_cascade(eng, orc, frames_small(4, 180, 320))
+    _check_cascade(eng, orc, truely_amd.synthetic.synthetic_frames(2, 97, 131, seed=21))
+
+
 def test_cascade_fused_pnet_720p(engine, oracle):
     out, ref = _check_cascade(engine, oracle, truely_amd.synthetic.synthetic_frames(3, 720, 1280, seed=0))
     assert ref["valid"].sum() >= 1

@@ -48,6 +48,7 @@ struct trl_ctx {
     int pnet_ev_used = 0;
     float last_ms[4] = {0, 0, 0, 0};
     int pnet_mono1 = 0;              // conv1 PReLU slopes all >= 0
+    int pnet_unit = 0;               // every PNet PReLU slope in [0, 1]
     uint32_t* pyr_tab = nullptr;     // pyramid bin-edge tables for the last (H, W)
     int pyr_tab_H = 0, pyr_tab_W = 0;
 };

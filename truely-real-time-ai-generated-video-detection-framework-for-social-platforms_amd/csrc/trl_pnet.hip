@@ -64,7 +64,7 @@ struct PnetArgs {
     const float *b1, *b2, *b3, *bh, *s1, *s2, *s3;
     float thr; int cap;
     int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); 0 in production
-    int mono1;                                 // 1: all conv1 PReLU slopes >= 0 (pool/PReLU may be swapped); 2: all in [0,1]
+    int mono1;                                 // all conv1 PReLU slopes >= 0 (pool/PReLU may be swapped)
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
 };
 
@@ -257,6 +257,12 @@ __device__ __forceinline__ int koff(int s, int kq, int e1, int e2, int e3) {
     return 4 * s + E * q0 + kq + add;
 }
 
+// UNIT: every PReLU slope of the net lies in [0, 1]; then prelu(v) == max(v, slope*v) exactly (two VALU ops instead
+// of three) and max-pool commutes with PReLU.  Any other weights take the generic instantiation.
+template <bool UNIT>
+__device__ __forceinline__ float prelu_t(float v, float sl) { return UNIT ? fmaxf(v, sl * v) : prelu(v, sl); }
+
+template <bool UNIT>
 __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
@@ -363,7 +369,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     int tile = t_begin + slot;
     TileId cur = decode(tile < t_end ? tile : 0), nxt = cur;
     if (tile < t_end) issue_input(cur);
-    for (; tile < t_end; tile += per_xcd_blocks, cur = nxt) {
+    int rot = 0;
+    for (; tile < t_end; tile += per_xcd_blocks, cur = nxt, rot++) {
         const int f = cur.f, l = cur.l, ty = cur.ty, tx = cur.tx;
         const PLevel& g = a.lv[l];
 
@@ -385,10 +392,10 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             const int vy = g.h - 2 - ty * 2 * TS, vx = g.w - 2 - tx * 2 * TS;   // valid conv1 extent inside the tile
             // max-pool commutes with PReLU when the slope is >= 0 (monotone): pool first, one PReLU per cell.
             // Interior tiles (every conv1 pixel of the tile inside the level) also skip the ceil-mode masks.
-            const bool fast = a.mono1 && vy >= 2 * P1_T && vx >= 2 * P1_T;
-            const bool unit = a.mono1 == 2;
-            auto conv1_pool = [&](auto FAST) {
-                constexpr bool kFast = decltype(FAST)::value;
+            const bool mono = UNIT || a.mono1;
+            const bool fast = mono && vy >= 2 * P1_T && vx >= 2 * P1_T;
+            auto conv1_pool = [&](auto MODE) {                      // 2: interior + monotone, 1: monotone, 0: generic
+                constexpr int kMode = decltype(MODE)::value;
                 float xs[2][14];
                 f32x4 acc[2][2];
                 auto read_tile = [&](int t, float* x) {             // t = 5*i + pg, compile time after unrolling
@@ -403,13 +410,18 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 auto pool_store = [&](const f32x4& v, int t) {
                     const int i = t / 5, pg = t % 5;
                     float outv;
-                    if (kFast) {
+                    const int py = wave + 4 * i;
+                    const bool r0 = 2 * py < vy, r1 = 2 * py + 1 < vy;
+                    const bool c0 = 8 * pg + 2 * kq < vx, c1 = 8 * pg + 2 * kq + 1 < vx;
+                    if (kMode == 2) {
                         const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                        outv = unit ? fmaxf(m, slope1 * m) : prelu(m, slope1);
+                        outv = prelu_t<UNIT>(m, slope1);
+                    } else if (kMode == 1) {                          // ceil-mode window clipped by the level edge
+                        const float ninf = -__builtin_inff();
+                        const float a1 = (r0 && c1) ? v[1] : ninf, a2 = (r1 && c0) ? v[2] : ninf, a3 = (r1 && c1) ? v[3] : ninf;
+                        const float m = fmaxf(fmaxf(v[0], a1), fmaxf(a2, a3));
+                        outv = (r0 && c0) ? prelu_t<UNIT>(m, slope1) : 0.f;
                     } else {
-                        const int py = wave + 4 * i;
-                        const bool r0 = 2 * py < vy, r1 = 2 * py + 1 < vy;
-                        const bool c0 = 8 * pg + 2 * kq < vx, c1 = 8 * pg + 2 * kq + 1 < vx;
                         const float v0 = prelu(v[0], slope1), v1 = prelu(v[1], slope1), v2 = prelu(v[2], slope1), v3 = prelu(v[3], slope1);
                         float m = v0;                                 // (dy,dx) = (0,0) is valid whenever the cell is
                         m = (r0 && c1 && v1 > m) ? v1 : m;
@@ -440,7 +452,9 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 }
                 pool_store(acc[0][0], 24);
             };
-            if (fast) conv1_pool(std::true_type{}); else conv1_pool(std::false_type{});
+            if (fast) conv1_pool(std::integral_constant<int, 2>{});
+            else if (mono) conv1_pool(std::integral_constant<int, 1>{});
+            else conv1_pool(std::integral_constant<int, 0>{});
         }
         __syncthreads();
 
@@ -450,31 +464,39 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             // RA (the input tile) is dead since the barrier above, so the epilogue may overwrite it.
             // The A operands of pair j+1 are requested right after the MFMAs of pair j are issued, so their LDS
             // latency hides under that pair's tail and epilogue (same registers: MFMA sources are read at issue).
+            // The 21 M-tiles split 6/5/5/5 over the waves; the 6-tile role rotates with the tile counter so that no
+            // SIMD (wave i of both resident workgroups sits on SIMD i) is the long pole every time.
+            const int w2 = (wave + rot) & 3;
             float xa[23], xb[23];
             auto read_pair2 = [&](int j) {
-                const int mtA = wave + 8 * j, mtB = (mtA + 4 < 21) ? mtA + 4 : mtA;
+                const int mtA = w2 + 8 * j, mtB = (mtA + 4 < 21) ? mtA + 4 : mtA;
                 int mA = mtA * 16 + l15; mA = mA < 324 ? mA : 323;
                 int mB = mtB * 16 + l15; mB = mB < 324 ? mB : 323;
                 const int yA = mA / C2_T, xA = mA - yA * C2_T, yB = mB / C2_T, xB = mB - yB * C2_T;
                 const int baseA = (yA * P1_T + xA) * 10, baseB = (yB * P1_T + xB) * 10;
 #pragma unroll
-                for (int s = 0; s < 23; s++) {
-                    const int ko = koff<30, 170>(s, kq, 0, e2_2, 0);
-                    xa[s] = RB[baseA + ko];
-                    xb[s] = RB[baseB + ko];
+                for (int s = 0; s < 23; s++) xa[s] = RB[baseA + koff<30, 170>(s, kq, 0, e2_2, 0)];
+                if (j < 2 || w2 == 0) {
+#pragma unroll
+                    for (int s = 0; s < 23; s++) xb[s] = RB[baseB + koff<30, 170>(s, kq, 0, e2_2, 0)];
                 }
             };
             read_pair2(0);
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                const int mtA = wave + 8 * j, mtB = mtA + 4;
-                const bool hasB = mtB < 21;
+                const int mtA = w2 + 8 * j, mtB = mtA + 4;
+                const bool hasB = mtB < 21;                    // j == 2: only wave role 0 has a second tile (M-tile 20)
                 f32x4 accA = {bias2, bias2, bias2, bias2}, accB = accA;
                 __builtin_amdgcn_sched_barrier(0);
+                if (j < 2 || hasB) {
 #pragma unroll
-                for (int s = 0; s < 23; s++) {
-                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B2[s], accB, 0, 0, 0);
+                    for (int s = 0; s < 23; s++) {
+                        accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B2[s], accB, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 23; s++) accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 2) read_pair2(j + 1);
@@ -482,9 +504,9 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int ra = mtA * 16 + kq * 4 + q;
-                    if (ra < 324) RA[ra * C2_LD + l15] = prelu(accA[q], slope2);
+                    if (ra < 324) RA[ra * C2_LD + l15] = prelu_t<UNIT>(accA[q], slope2);
                     const int rb = mtB * 16 + kq * 4 + q;
-                    if (hasB && rb < 324) RA[rb * C2_LD + l15] = prelu(accB[q], slope2);
+                    if (hasB && rb < 324) RA[rb * C2_LD + l15] = prelu_t<UNIT>(accB[q], slope2);
                 }
             }
         }
@@ -521,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-                    ST[row * ST_LD + l31] = prelu(acc[q], slope3);
+                    ST[row * ST_LD + l31] = prelu_t<UNIT>(acc[q], slope3);
                 }
                 __builtin_amdgcn_wave_barrier();
                 // heads: two 16-row M-tiles, K = 32
@@ -587,10 +609,14 @@ int trl_pnet_prepare(trl_ctx* c) {
     }
     float sl[10];
     TRL_HIP(hipMemcpy(sl, trl_v(c, "pnet.prelu1")->p, sizeof sl, hipMemcpyDeviceToHost));
-    c->pnet_mono1 = 2;
-    for (float v : sl) {
-        if (!(v <= 1.f) && c->pnet_mono1 == 2) c->pnet_mono1 = 1;
-        if (!(v >= 0.f)) c->pnet_mono1 = 0;
+    c->pnet_mono1 = 1;
+    for (float v : sl) if (!(v >= 0.f)) c->pnet_mono1 = 0;
+    c->pnet_unit = 1;
+    for (const char* n : {"pnet.prelu1", "pnet.prelu2", "pnet.prelu3"}) {
+        const DevV* v = trl_v(c, n);
+        std::vector<float> h(v->n);
+        TRL_HIP(hipMemcpy(h.data(), v->p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (float x : h) if (!(x >= 0.f && x <= 1.f)) c->pnet_unit = 0;
     }
     return TRL_OK;
 }
@@ -706,7 +732,8 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     int grid = 256 * 2;                       // 2 resident workgroups per CU (<= 256 VGPRs)
     if (grid > ((total_tiles + 7) / 8) * 8) grid = ((total_tiles + 7) / 8) * 8;
     if (grid < 8) grid = 8;
-    k_pnet_fused<<<grid, 256, 0, s>>>(a);
+    if (c->pnet_unit) k_pnet_fused<true><<<grid, 256, 0, s>>>(a);
+    else k_pnet_fused<false><<<grid, 256, 0, s>>>(a);
     TRL_LAUNCH_CHECK();
     if (ev) TRL_HIP(hipEventRecord(ev[3], s));
     return TRL_OK;
