@@ -527,18 +527,25 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 f32x16 acc;
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[q] = bias3;
+                // 6 x 12 k-steps, double buffered: the operands of sixth i+1 are requested before the MFMAs of sixth i
+                // issue, so only the first sixth's LDS latency is exposed.
+                float xa[2][12], wb[2][12];
+                auto read_sixth = [&](int sx, float* xo, float* wo) {
 #pragma unroll
-                for (int half = 0; half < 3; half++) {      // 3 x 24 k-steps: both operands of a third are in flight first
-                    float xa[24], wb[24];
-#pragma unroll
-                    for (int u = 0; u < 24; u++) {
-                        const int s = half * 24 + u, tap = s >> 3, ky = tap / 3, kx = tap - ky * 3;
-                        xa[u] = RA[base + (ky * C2_T + kx) * C2_LD + 2 * (s & 7)];
-                        wb[u] = B3S[(2 * s + hh) * 32 + l31];
+                    for (int u = 0; u < 12; u++) {
+                        const int s = sx * 12 + u, tap = s >> 3, ky = tap / 3, kx = tap - ky * 3;
+                        xo[u] = RA[base + (ky * C2_T + kx) * C2_LD + 2 * (s & 7)];
+                        wo[u] = B3S[(2 * s + hh) * 32 + l31];
                     }
+                };
+                read_sixth(0, xa[0], wb[0]);
+#pragma unroll
+                for (int sx = 0; sx < 6; sx++) {
+                    if (sx < 5) read_sixth(sx + 1, xa[(sx + 1) & 1], wb[(sx + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < 24; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u], wb[u], acc, 0, 0, 0);
+                    for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[sx & 1][u], wb[sx & 1][u], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
