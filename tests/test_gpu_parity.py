@@ -126,14 +126,15 @@ def test_cascade_fused_pnet_prelu_variants(variant):
     from truely_amd.engine import Engine
     from truely_amd import weights
     sds = [dict(sd) for sd in weights.synthetic_state_dicts(0)]
-    pnet = sds[0]
-    for key in ("prelu1.weight", "prelu2.weight", "prelu3.weight"):
-        w = np.array(pnet[key], np.float32, copy=True)
-        if variant == "slopes_above_one":
-            w[::2] = 1.25
-        else:
-            w[1::3] = -0.2
-        pnet[key] = w
+    for net, keys in ((sds[0], ("prelu1.weight", "prelu2.weight", "prelu3.weight")), (sds[1], ("prelu1.weight",)),
+                      (sds[2], ("prelu1.weight",))):          # PNet (fused kernel) and the R-/O-Net front kernels
+        for key in keys:
+            w = np.array(net[key], np.float32, copy=True)
+            if variant == "slopes_above_one":
+                w[::2] = 1.25
+            else:
+                w[1::3] = -0.2
+            net[key] = w
     blob = weights.pack_state_dicts(*sds)
     eng, orc = Engine(blob), Oracle(blob)
     _check_cascade(eng, orc, frames_small(4, 180, 320))

@@ -242,6 +242,7 @@ extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
     }
 
     TRL_CHECK(trl_pnet_prepare(c));
+    c->rnet_front_mode = c->onet_front_mode = -1;
     c->have_weights = true;
     return TRL_OK;
 }

@@ -5,6 +5,7 @@
 // which removes ~7.6 GB of HBM traffic per 256-frame batch.  conv1 runs on v_mfma_f32_16x16x4_f32 with the
 // weights in registers, k ascending from the bias: bit-identical to the oracle's conv2d chain.
 #include "trl_ctx.h"
+#include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -18,7 +19,11 @@ __device__ __forceinline__ void pad_box(const float* b, int W, int H, int& y, in
     ey = bey > H ? H : bey;
 }
 
-template <int S, int C1, int CLD, int R>
+// MODE: 0 = generic PReLU, applied to every conv1 output before the pool (the reference order);
+//       1 = all slopes >= 0: PReLU is monotone, so it commutes with max and is applied once per POOLED value;
+//       2 = all slopes in [0, 1]: as 1, with prelu(v) == max(v, slope*v) (exact, one VALU op fewer).
+// The kernel is VALU-bound (crop unpacking, pooling), and VALU shares the FP32 pipe with the f32 MFMAs.
+template <int S, int C1, int R, int MODE>
 __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__ frames, int nframes, int H, int W, int capF,
                                                      const float* __restrict__ boxes, const int32_t* __restrict__ map_frame,
                                                      const int32_t* __restrict__ map_local, int t0, const float* __restrict__ w1,
@@ -28,13 +33,16 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
     constexpr int P = (CW - 3 + 1) / 2 + 1;          // MaxPool(3,2,ceil) output side (11 / 23)
     constexpr int SR = 2 * R + 1;                    // conv1 rows per strip
     constexpr int IN_N = S * S * 3;
+    constexpr int CLD = 36;                          // channel stride of the conv1 strip: float4 pooling reads, and the
+                                                     // epilogue's rows 4*kq+q land 16 banks apart (conflict free)
+    constexpr int MROWS = (SR * CW + 15) & ~15;      // strip rows padded to whole M-tiles: unguarded epilogue stores
     __shared__ __attribute__((aligned(16))) float in_s[IN_N + 128];
-    __shared__ __attribute__((aligned(16))) float c1_s[SR * CW * CLD];
+    __shared__ __attribute__((aligned(16))) float c1_s[MROWS * CLD];
     // per-wave column-sum strip (aliases c1_s, which is dead during the crop)
-    constexpr int COLCAP = ((SR * CW * CLD - 16) / 4 < 2048 ? (SR * CW * CLD - 16) / 4 : 2048) & ~3;
+    constexpr int COLCAP = ((MROWS * CLD - 16) / 4 < 2048 ? (MROWS * CLD - 16) / 4 : 2048) & ~3;
     static_assert(COLCAP >= 1024, "column strip too small");
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int t = t0 + blockIdx.x;
 
@@ -144,69 +152,101 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
     __syncthreads();
 
     float* dst = out + (size_t)blockIdx.x * P * P * C1;
+    auto act = [&](float v, float sl) { return MODE == 2 ? fmaxf(v, sl * v) : (v > 0.f ? v : sl * v); };
+    float* const erow = c1_s + (kq * 4) * CLD + l15;             // epilogue lane base: row 4*kq (+q), channel l15
     for (int p0 = 0; p0 < P; p0 += R) {
         const int rows0 = 2 * p0;
         const int nrows = (CW - rows0) < SR ? (CW - rows0) : SR;
         const int M = nrows * CW;
         const int ntiles = (M + 15) >> 4;
-        // two M-tiles x two N-tiles = four independent accumulator chains per wave
+        // two M-tiles x two N-tiles = four independent accumulator chains per wave (the M-tile index is scalar)
         for (int mt = wave; mt < ntiles; mt += 8) {
-            const int mtB = mt + 4;
-            const bool hasB = mtB < ntiles;
+            const bool hasB = mt + 4 < ntiles;
             int mA = mt * 16 + l15; mA = mA < M ? mA : M - 1;
-            int mB = (hasB ? mtB : mt) * 16 + l15; mB = mB < M ? mB : M - 1;
-            const int yA = mA / CW, xA = mA - yA * CW, yB = mB / CW, xB = mB - yB * CW;
-            const int baseA = ((rows0 + yA) * S + xA) * 3, baseB = ((rows0 + yB) * S + xB) * 3;
+            const int yA = mA / CW, xA = mA - yA * CW;
+            const int baseA = ((rows0 + yA) * S + xA) * 3;
             f32x4 a0 = {bias0, bias0, bias0, bias0}, a1 = {bias1, bias1, bias1, bias1}, c0 = a0, c1 = a1;
+            if (hasB) {
+                int mB = (mt + 4) * 16 + l15; mB = mB < M ? mB : M - 1;
+                const int yB = mB / CW, xB = mB - yB * CW;
+                const int baseB = ((rows0 + yB) * S + xB) * 3;
+                float xa[7], xb[7];
 #pragma unroll
-            for (int s = 0; s < 7; s++) {
-                const float xa = in_s[baseA + koff[s]];
-                const float xb = in_s[baseB + koff[s]];
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, B0[s], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, B1[s], a1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, B0[s], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, B1[s], c1, 0, 0, 0);
+                for (int s = 0; s < 7; s++) { xa[s] = in_s[baseA + koff[s]]; xb[s] = in_s[baseB + koff[s]]; }
+#pragma unroll
+                for (int s = 0; s < 7; s++) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B0[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B1[s], a1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B0[s], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B1[s], c1, 0, 0, 0);
+                }
+            } else {
+                float xa[7];
+#pragma unroll
+                for (int s = 0; s < 7; s++) xa[s] = in_s[baseA + koff[s]];
+#pragma unroll
+                for (int s = 0; s < 7; s++) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B0[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B1[s], a1, 0, 0, 0);
+                }
             }
+            // rows past M and channels past C1 fall into the strip's padding: nothing reads them
+            float* ea = erow + mt * (16 * CLD);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int ra = mt * 16 + kq * 4 + q;
-                if (ra < M) {
-                    const float v0 = a0[q], v1 = a1[q];
-                    c1_s[ra * CLD + l15] = v0 > 0.f ? v0 : sl0 * v0;
-                    if (16 + l15 < C1) c1_s[ra * CLD + 16 + l15] = v1 > 0.f ? v1 : sl1 * v1;
-                }
-                const int rb = mtB * 16 + kq * 4 + q;
-                if (hasB && rb < M) {
-                    const float v0 = c0[q], v1 = c1[q];
-                    c1_s[rb * CLD + l15] = v0 > 0.f ? v0 : sl0 * v0;
-                    if (16 + l15 < C1) c1_s[rb * CLD + 16 + l15] = v1 > 0.f ? v1 : sl1 * v1;
+                ea[q * CLD] = MODE == 0 ? act(a0[q], sl0) : a0[q];
+                ea[q * CLD + 16] = MODE == 0 ? act(a1[q], sl1) : a1[q];
+            }
+            if (hasB) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    ea[(64 + q) * CLD] = MODE == 0 ? act(c0[q], sl0) : c0[q];
+                    ea[(64 + q) * CLD + 16] = MODE == 0 ? act(c1[q], sl1) : c1[q];
                 }
             }
         }
         __syncthreads();
-        // ---- MaxPool(3, 2, ceil_mode) of the strip -> global NHWC [P][P][C1] -------------------------------------
+        // ---- MaxPool(3, 2, ceil_mode) of the strip -> global NHWC [P][P][C1], four channels per thread ------------
         const int prow = (P - p0) < R ? (P - p0) : R;
-        for (int idx = tid; idx < prow * P * C1; idx += 256) {
-            const int c = idx % C1;
-            const int px = (idx / C1) % P;
-            const int pr = idx / (C1 * P);
-            float best = -INFINITY;
+        constexpr int C4 = C1 / 4;
+        for (int idx = tid; idx < prow * P * C4; idx += 256) {
+            const int c4 = idx % C4;
+            const int px = (idx / C4) % P;
+            const int pr = idx / (C4 * P);
+            const float* src = c1_s + ((2 * pr) * CW + 2 * px) * CLD + 4 * c4;
+            float4 best = *reinterpret_cast<const float4*>(src);      // (dy, dx) = (0, 0) always exists
+            const bool x2 = 2 * px + 2 < CW;                          // ceil mode: the last window is clipped
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
-                const int yy = 2 * pr + dy;
-                if (yy >= nrows) break;
+                if (2 * pr + dy >= nrows) break;
 #pragma unroll
                 for (int dx = 0; dx < 3; dx++) {
-                    const int xx = 2 * px + dx;
-                    if (xx >= CW) break;
-                    const float v = c1_s[(yy * CW + xx) * CLD + c];
-                    best = v > best ? v : best;
+                    if (dy == 0 && dx == 0) continue;
+                    if (dx == 2 && !x2) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(src + (dy * CW + dx) * CLD);
+                    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
                 }
             }
-            dst[((size_t)(p0 + pr) * P + px) * C1 + c] = best;
+            if (MODE != 0) {
+                const float4 sl = *reinterpret_cast<const float4*>(s1 + 4 * c4);
+                best.x = act(best.x, sl.x); best.y = act(best.y, sl.y); best.z = act(best.z, sl.z); best.w = act(best.w, sl.w);
+            }
+            *reinterpret_cast<float4*>(dst + ((size_t)(p0 + pr) * P + px) * C1 + 4 * c4) = best;
         }
         __syncthreads();
     }
+}
+
+// conv1 PReLU slope class of a net (see MODE above)
+int slope_mode(const DevV* sl, int n) {
+    std::vector<float> h(n);
+    if (hipMemcpy(h.data(), sl->p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    int mode = 2;
+    for (float v : h) {
+        if (!(v >= 0.f)) return 0;
+        if (!(v <= 1.f)) mode = 1;
+    }
+    return mode;
 }
 
 }  // namespace
@@ -218,8 +258,11 @@ int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     const DevW* w = trl_w(c, "rnet.conv1.w");
     const DevV *b = trl_v(c, "rnet.conv1.b"), *sl = trl_v(c, "rnet.prelu1");
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("rnet.conv1 weights"); return TRL_ERR_WEIGHTS; }
-    k_mtcnn_front<24, 28, 29, 4><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, c->cb.map_local, t0, w->p,
-                                                      b->p, sl->p, d_pool);
+    if (c->rnet_front_mode < 0) c->rnet_front_mode = slope_mode(sl, 28);
+#define TRL_RF(MODE) k_mtcnn_front<24, 28, 4, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
+                                                                       c->cb.map_local, t0, w->p, b->p, sl->p, d_pool)
+    if (c->rnet_front_mode == 2) TRL_RF(2); else if (c->rnet_front_mode == 1) TRL_RF(1); else TRL_RF(0);
+#undef TRL_RF
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
@@ -230,8 +273,11 @@ int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     const DevW* w = trl_w(c, "onet.conv1.w");
     const DevV *b = trl_v(c, "onet.conv1.b"), *sl = trl_v(c, "onet.prelu1");
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("onet.conv1 weights"); return TRL_ERR_WEIGHTS; }
-    k_mtcnn_front<48, 32, 33, 2><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, c->cb.map_local, t0, w->p,
-                                                     b->p, sl->p, d_pool);
+    if (c->onet_front_mode < 0) c->onet_front_mode = slope_mode(sl, 32);
+#define TRL_OF(MODE) k_mtcnn_front<48, 32, 3, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
+                                                                       c->cb.map_local, t0, w->p, b->p, sl->p, d_pool)
+    if (c->onet_front_mode == 2) TRL_OF(2); else if (c->onet_front_mode == 1) TRL_OF(1); else TRL_OF(0);
+#undef TRL_OF
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
