@@ -89,34 +89,54 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                 const int xeb = (oxb * iw + S - 1) / S;
                 const int seg_bytes = (xeb - xsa) * 3;
                 // four 256-byte chunks x four source rows per pass: 32 independent dword loads are in flight before
-                // any is consumed (the crop is latency-bound: one wave owns the row, nothing else hides the latency)
-                const long long o_safe = fbyte0 + ((long long)(y0 + ys) * W + x0 + xsa) * 3;
+                // any is consumed (one wave owns the row, nothing else hides the latency).  All addressing is a scalar
+                // row base plus a clamped 32-bit lane offset, the re-alignment shift is a scalar per row, and bytes
+                // accumulate in packed 16-bit halves (<= 256 rows x 255 per flush): ~9 VALU per dword.
+                const long long o_seg = fbyte0 + ((long long)(y0 + ys) * W + x0 + xsa) * 3;
                 const long long row_pitch = (long long)W * 3;
                 for (int c0 = 0; c0 < seg_bytes; c0 += 1024) {
                     unsigned sum[4][4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) { sum[c][0] = 0; sum[c][1] = 0; sum[c][2] = 0; sum[c][3] = 0; }
-                    for (int yy = ys; yy < ye; yy += 4) {
-                        unsigned lo[4][4], hi[4][4], shv[4][4];
+                    for (int yb = ys; yb < ye; yb += 256) {
+                        const int yl = (ye - yb) < 256 ? (ye - yb) : 256;
+                        unsigned ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};   // bytes 0,2 / 1,3 of each dword column
+                        for (int yy = 0; yy < yl; yy += 4) {
+                            unsigned lo[4][4], hi[4][4];
+                            unsigned shr[4];
 #pragma unroll
-                        for (int r = 0; r < 4; r++)
-#pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                const int b = c0 + 256 * c + 4 * lane;
-                                const bool act = (yy + r < ye) && (b < seg_bytes);
-                                const long long o = act ? o_safe + (long long)(yy + r - ys) * row_pitch + b : o_safe;
+                            for (int r = 0; r < 4; r++) {
+                                const int rr = (yy + r < yl) ? yy + r : 0;                        // inactive rows re-read row 0
+                                const long long o = o_seg + (long long)(yb - ys + rr) * row_pitch + c0;   // scalar
                                 const long long dw = o >> 2;
-                                lo[r][c] = base32[dw];
-                                hi[r][c] = base32[dw < last_dw ? dw + 1 : last_dw];
-                                shv[r][c] = act ? (unsigned)(o & 3) : 4u;   // 4 = inactive marker
+                                shr[r] = (unsigned)(o & 3);
+                                const long long room = last_dw - dw;                               // >= 0: byte o is a frame byte
+                                const unsigned lim = room > 0x3fffffll ? 0xfffffcu : (unsigned)room * 4u;
+                                const char* rowp = reinterpret_cast<const char*>(base32 + dw);
+#pragma unroll
+                                for (int c = 0; c < 4; c++) {
+                                    const unsigned ob = 256u * c + 4u * lane;
+                                    lo[r][c] = *reinterpret_cast<const uint32_t*>(rowp + (ob < lim ? ob : lim));
+                                    hi[r][c] = *reinterpret_cast<const uint32_t*>(rowp + (ob + 4u < lim ? ob + 4u : lim));
+                                }
                             }
 #pragma unroll
-                        for (int r = 0; r < 4; r++)
+                            for (int r = 0; r < 4; r++) {
+                                const bool live = yy + r < yl;
 #pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                const unsigned v = shv[r][c] < 4u ? __builtin_amdgcn_alignbyte(hi[r][c], lo[r][c], shv[r][c]) : 0u;
-                                sum[c][0] += v & 0xFFu; sum[c][1] += (v >> 8) & 0xFFu; sum[c][2] += (v >> 16) & 0xFFu; sum[c][3] += v >> 24;
+                                for (int c = 0; c < 4; c++) {
+                                    unsigned v = __builtin_amdgcn_alignbyte(hi[r][c], lo[r][c], shr[r]);
+                                    v = live ? v : 0u;
+                                    ev[c] += v & 0x00FF00FFu;
+                                    od[c] += (v >> 8) & 0x00FF00FFu;
+                                }
                             }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            sum[c][0] += ev[c] & 0xFFFFu; sum[c][2] += ev[c] >> 16;
+                            sum[c][1] += od[c] & 0xFFFFu; sum[c][3] += od[c] >> 16;
+                        }
                     }
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
