@@ -5,6 +5,7 @@
 // which removes ~7.6 GB of HBM traffic per 256-frame batch.  conv1 runs on v_mfma_f32_16x16x4_f32 with the
 // weights in registers, k ascending from the bias: bit-identical to the oracle's conv2d chain.
 #include "trl_ctx.h"
+#include <stdlib.h>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -19,6 +20,13 @@ __device__ __forceinline__ void pad_box(const float* b, int W, int H, int& y, in
     ey = bey > H ? H : bey;
 }
 
+typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at dword alignment
+
+__device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF for bytes b of the dword with rel+b < nbytes
+    int hi = nbytes - rel; hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+    return hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
+}
+
 // MODE: 0 = generic PReLU, applied to every conv1 output before the pool (the reference order);
 //       1 = all slopes >= 0: PReLU is monotone, so it commutes with max and is applied once per POOLED value;
 //       2 = all slopes in [0, 1]: as 1, with prelu(v) == max(v, slope*v) (exact, one VALU op fewer).
@@ -28,7 +36,7 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                                                      const float* __restrict__ boxes, const int32_t* __restrict__ map_frame,
                                                      const int32_t* __restrict__ map_local, int t0, const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ s1,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, int dbg_skip) {
     constexpr int CW = S - 2;                        // conv1 output side
     constexpr int P = (CW - 3 + 1) / 2 + 1;          // MaxPool(3,2,ceil) output side (11 / 23)
     constexpr int SR = 2 * R + 1;                    // conv1 rows per strip
@@ -59,101 +67,174 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
         const long long last_dw = ((long long)nframes * H * W * 3 - 1) >> 2;   // last dword holding frame bytes
         const long long fbyte0 = (long long)f * H * W * 3;
         unsigned* colbuf = reinterpret_cast<unsigned*>(c1_s) + wave * COLCAP;
-        if (ih <= 3 * S && iw <= 3 * S) {
-            // small boxes (bins of at most 4x4 pixels): one thread per output pixel, all loads independent
-            const uint8_t* fp = frames + fbyte0;
-            for (int p = tid; p < S * S; p += 256) {
-                const int oy = p / S, ox = p - oy * S;
-                const int ys = (oy * ih) / S, ye = ((oy + 1) * ih + S - 1) / S;
-                const int xs = (ox * iw) / S, xe = ((ox + 1) * iw + S - 1) / S;
-                unsigned a0 = 0, a1 = 0, a2 = 0;
-                for (int yy = ys; yy < ye; yy++) {
-                    const uint8_t* q = fp + ((size_t)(y0 + yy) * W + x0 + xs) * 3;
-                    for (int xx = xs; xx < xe; xx++, q += 3) { a0 += q[0]; a1 += q[1]; a2 += q[2]; }
+        if (dbg_skip & 1) {
+            for (int p = tid; p < IN_N; p += 256) in_s[p] = 0.f;
+        } else if (ih <= 3 * S && iw <= 3 * S) {
+            // small boxes: bins of at most 4x4 pixels, i.e. <= 12 bytes per source row = one dword-aligned 16-byte load.
+            // One thread per output pixel, three pixels per pass: all 12 row loads are issued before any is consumed
+            // (one memory round trip per pass instead of one per tap); bytes -> channel sums with v_alignbyte + v_dot4.
+            const long long row_bytes = (long long)W * 3;
+            for (int pb = tid; pb < S * S; pb += 3 * 256) {
+                unsigned ww[3][4][4], shv[3][4];
+                int khv[3], kwv[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int pp = pb + 256 * u, p = pp < S * S ? pp : 0;
+                    const int oy = p / S, ox = p - oy * S;
+                    const int ys = (oy * ih) / S, ye = ((oy + 1) * ih + S - 1) / S;
+                    const int xs = (ox * iw) / S, xe = ((ox + 1) * iw + S - 1) / S;
+                    khv[u] = ye - ys; kwv[u] = xe - xs;
+                    const long long o0 = fbyte0 + ((long long)(y0 + ys) * W + x0 + xs) * 3;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const long long o = o0 + (long long)(r < khv[u] ? r : (khv[u] > 0 ? khv[u] - 1 : 0)) * row_bytes;
+                        const long long dw = o >> 2;
+                        shv[u][r] = (unsigned)(o & 3);
+                        if (dw + 3 <= last_dw) {
+                            const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(base32 + dw);
+                            ww[u][r][0] = v4[0]; ww[u][r][1] = v4[1]; ww[u][r][2] = v4[2]; ww[u][r][3] = v4[3];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) ww[u][r][j] = base32[dw + j <= last_dw ? dw + j : last_dw];
+                        }
+                    }
                 }
-                const float kh = (float)(ye - ys), kw = (float)(xe - xs);
-                in_s[3 * p + 0] = ((float)a0 / kh / kw - 127.5f) * 0.0078125f;
-                in_s[3 * p + 1] = ((float)a1 / kh / kw - 127.5f) * 0.0078125f;
-                in_s[3 * p + 2] = ((float)a2 / kh / kw - 127.5f) * 0.0078125f;
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int nbytes = kwv[u] * 3;
+                    const unsigned vm0 = valid_bytes(0, nbytes), vm1 = valid_bytes(4, nbytes), vm2 = valid_bytes(8, nbytes);
+                    unsigned a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const bool live = r < khv[u];
+                        const unsigned sh = shv[u][r];
+                        const unsigned d0 = __builtin_amdgcn_alignbyte(ww[u][r][1], ww[u][r][0], sh) & (live ? vm0 : 0u);
+                        const unsigned d1 = __builtin_amdgcn_alignbyte(ww[u][r][2], ww[u][r][1], sh) & (live ? vm1 : 0u);
+                        const unsigned d2 = __builtin_amdgcn_alignbyte(ww[u][r][3], ww[u][r][2], sh) & (live ? vm2 : 0u);
+                        a0 = __builtin_amdgcn_udot4(d0, 0x01000001u, a0, false); a1 = __builtin_amdgcn_udot4(d0, 0x00000100u, a1, false);
+                        a2 = __builtin_amdgcn_udot4(d0, 0x00010000u, a2, false);
+                        a0 = __builtin_amdgcn_udot4(d1, 0x00010000u, a0, false); a1 = __builtin_amdgcn_udot4(d1, 0x01000001u, a1, false);
+                        a2 = __builtin_amdgcn_udot4(d1, 0x00000100u, a2, false);
+                        a0 = __builtin_amdgcn_udot4(d2, 0x00000100u, a0, false); a1 = __builtin_amdgcn_udot4(d2, 0x00010000u, a1, false);
+                        a2 = __builtin_amdgcn_udot4(d2, 0x01000001u, a2, false);
+                    }
+                    const int pp = pb + 256 * u;
+                    if (pp < S * S) {
+                        const float kh = (float)khv[u], kw = (float)kwv[u];
+                        in_s[3 * pp + 0] = ((float)a0 / kh / kw - 127.5f) * 0.0078125f;
+                        in_s[3 * pp + 1] = ((float)a1 / kh / kw - 127.5f) * 0.0078125f;
+                        in_s[3 * pp + 2] = ((float)a2 / kh / kw - 127.5f) * 0.0078125f;
+                    }
+                }
             }
-        } else
-        for (int oy = wave; oy < S; oy += 4) {
-            const int ys = (oy * ih) / S, ye = ((oy + 1) * ih + S - 1) / S;
-            const float kh = (float)(ye - ys);
-            int oxa = 0;
-            while (oxa < S) {
-                // segment of output columns whose source span fits the strip
-                const int xsa = (oxa * iw) / S;
-                int oxb = oxa + 1;
-                while (oxb < S && (((oxb + 1) * iw + S - 1) / S - xsa) * 3 <= COLCAP) oxb++;
-                const int xeb = (oxb * iw + S - 1) / S;
-                const int seg_bytes = (xeb - xsa) * 3;
-                // four 256-byte chunks x four source rows per pass: 32 independent dword loads are in flight before
-                // any is consumed (one wave owns the row, nothing else hides the latency).  All addressing is a scalar
-                // row base plus a clamped 32-bit lane offset, the re-alignment shift is a scalar per row, and bytes
-                // accumulate in packed 16-bit halves (<= 256 rows x 255 per flush): ~9 VALU per dword.
-                const long long o_seg = fbyte0 + ((long long)(y0 + ys) * W + x0 + xsa) * 3;
-                const long long row_pitch = (long long)W * 3;
-                for (int c0 = 0; c0 < seg_bytes; c0 += 1024) {
-                    unsigned sum[4][4];
+        } else {
+            // big boxes: a wave owns output rows oy = wave (mod 4) and works on TWO of them (oy, oy+4) in lock step, so
+            // 32 independent dword loads (2 bins x 4 source rows x 4 chunks) are in flight per round trip -- the crop is
+            // bound by dependent round trips, not by bytes.  A chunk is 63 payload dwords: lane i re-aligns dword i
+            // with dword i+1 taken from lane i+1 by a DPP wave shift (no second load); lane 63 only feeds lane 62.
+            // Addressing is a scalar row base plus a clamped 32-bit lane offset, the re-alignment shift is a scalar per
+            // row, bytes accumulate in packed 16-bit halves (<= 256 rows x 255 per flush).
+            static_assert((S / 4) % 2 == 0, "rows per wave must pair up");
+            constexpr int CAP2 = (COLCAP / 2) & ~3;
+            unsigned* colA = colbuf;
+            unsigned* colB = colbuf + CAP2;
+            const long long row_pitch = (long long)W * 3;
+            for (int oyA = wave; oyA < S; oyA += 8) {
+                const int oyB = oyA + 4;
+                const int ysA = (oyA * ih) / S, yeA = ((oyA + 1) * ih + S - 1) / S, khA = yeA - ysA;
+                const int ysB = (oyB * ih) / S, yeB = ((oyB + 1) * ih + S - 1) / S, khB = yeB - ysB;
+                const int khm = khA > khB ? khA : khB;
+                int oxa = 0;
+                while (oxa < S) {
+                    // segment of output columns whose source span fits half the strip
+                    const int xsa = (oxa * iw) / S;
+                    int oxb = oxa + 1;
+                    while (oxb < S && (((oxb + 1) * iw + S - 1) / S - xsa) * 3 <= CAP2 - 4) oxb++;
+                    const int xeb = (oxb * iw + S - 1) / S;
+                    const int seg_bytes = (xeb - xsa) * 3;
+                    const long long o_segA = fbyte0 + ((long long)(y0 + ysA) * W + x0 + xsa) * 3;
+                    const long long o_segB = fbyte0 + ((long long)(y0 + ysB) * W + x0 + xsa) * 3;
+                    for (int c0 = 0; c0 < seg_bytes; c0 += 4 * 252) {
+                        unsigned sum[2][4][4];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) { sum[c][0] = 0; sum[c][1] = 0; sum[c][2] = 0; sum[c][3] = 0; }
-                    for (int yb = ys; yb < ye; yb += 256) {
-                        const int yl = (ye - yb) < 256 ? (ye - yb) : 256;
-                        unsigned ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};   // bytes 0,2 / 1,3 of each dword column
-                        for (int yy = 0; yy < yl; yy += 4) {
-                            unsigned lo[4][4], hi[4][4];
-                            unsigned shr[4];
+                        for (int z = 0; z < 2; z++)
 #pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const int rr = (yy + r < yl) ? yy + r : 0;                        // inactive rows re-read row 0
-                                const long long o = o_seg + (long long)(yb - ys + rr) * row_pitch + c0;   // scalar
-                                const long long dw = o >> 2;
-                                shr[r] = (unsigned)(o & 3);
-                                const long long room = last_dw - dw;                               // >= 0: byte o is a frame byte
-                                const unsigned lim = room > 0x3fffffll ? 0xfffffcu : (unsigned)room * 4u;
-                                const char* rowp = reinterpret_cast<const char*>(base32 + dw);
+                            for (int c = 0; c < 4; c++) { sum[z][c][0] = 0; sum[z][c][1] = 0; sum[z][c][2] = 0; sum[z][c][3] = 0; }
+                        for (int yb = 0; yb < khm; yb += 256) {
+                            const int yl = (khm - yb) < 256 ? (khm - yb) : 256;
+                            unsigned ev[2][4], od[2][4];                 // bytes 0,2 / 1,3 of each dword column
 #pragma unroll
-                                for (int c = 0; c < 4; c++) {
-                                    const unsigned ob = 256u * c + 4u * lane;
-                                    lo[r][c] = *reinterpret_cast<const uint32_t*>(rowp + (ob < lim ? ob : lim));
-                                    hi[r][c] = *reinterpret_cast<const uint32_t*>(rowp + (ob + 4u < lim ? ob + 4u : lim));
-                                }
+                            for (int z = 0; z < 2; z++)
+#pragma unroll
+                                for (int c = 0; c < 4; c++) { ev[z][c] = 0; od[z][c] = 0; }
+                            for (int yy = 0; yy < yl; yy += 4) {
+                                unsigned lo[2][4][4];
+                                unsigned shr[2][4];
+#pragma unroll
+                                for (int z = 0; z < 2; z++)
+#pragma unroll
+                                    for (int r = 0; r < 4; r++) {
+                                        const int kh_z = z ? khB : khA;
+                                        const int rr = (yb + yy + r < kh_z) ? yb + yy + r : 0;              // dead rows re-read row 0
+                                        const long long o = (z ? o_segB : o_segA) + (long long)rr * row_pitch + c0;   // scalar
+                                        const long long dw = o >> 2;
+                                        shr[z][r] = (unsigned)(o & 3);
+                                        const long long room = last_dw - dw;                             // >= 0: byte o is a frame byte
+                                        const unsigned lim = room > 0x3fffffll ? 0xfffffcu : (unsigned)room * 4u;
+                                        const char* rowp = reinterpret_cast<const char*>(base32 + dw);
+#pragma unroll
+                                        for (int c = 0; c < 4; c++) {
+                                            const unsigned ob = 252u * c + 4u * lane;
+                                            lo[z][r][c] = *reinterpret_cast<const uint32_t*>(rowp + (ob < lim ? ob : lim));
+                                        }
+                                    }
+#pragma unroll
+                                for (int z = 0; z < 2; z++)
+#pragma unroll
+                                    for (int r = 0; r < 4; r++) {
+                                        const bool live = yb + yy + r < (z ? khB : khA);
+#pragma unroll
+                                        for (int c = 0; c < 4; c++) {
+                                            const unsigned l = lo[z][r][c];
+                                            const unsigned h = (unsigned)__builtin_amdgcn_update_dpp((int)l, (int)l, 0x130, 0xF, 0xF, false);   // wave_shl:1
+                                            unsigned v = __builtin_amdgcn_alignbyte(h, l, shr[z][r]);
+                                            v = live ? v : 0u;
+                                            ev[z][c] += v & 0x00FF00FFu;
+                                            od[z][c] += (v >> 8) & 0x00FF00FFu;
+                                        }
+                                    }
                             }
 #pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const bool live = yy + r < yl;
+                            for (int z = 0; z < 2; z++)
 #pragma unroll
                                 for (int c = 0; c < 4; c++) {
-                                    unsigned v = __builtin_amdgcn_alignbyte(hi[r][c], lo[r][c], shr[r]);
-                                    v = live ? v : 0u;
-                                    ev[c] += v & 0x00FF00FFu;
-                                    od[c] += (v >> 8) & 0x00FF00FFu;
+                                    sum[z][c][0] += ev[z][c] & 0xFFFFu; sum[z][c][2] += ev[z][c] >> 16;
+                                    sum[z][c][1] += od[z][c] & 0xFFFFu; sum[z][c][3] += od[z][c] >> 16;
                                 }
-                            }
                         }
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
-                            sum[c][0] += ev[c] & 0xFFFFu; sum[c][2] += ev[c] >> 16;
-                            sum[c][1] += od[c] & 0xFFFFu; sum[c][3] += od[c] >> 16;
+                            const int b = c0 + 252 * c + 4 * lane;
+                            if (lane < 63 && b < seg_bytes) {
+                                colA[b] = sum[0][c][0]; colA[b + 1] = sum[0][c][1]; colA[b + 2] = sum[0][c][2]; colA[b + 3] = sum[0][c][3];
+                                colB[b] = sum[1][c][0]; colB[b + 1] = sum[1][c][1]; colB[b + 2] = sum[1][c][2]; colB[b + 3] = sum[1][c][3];
+                            }
                         }
                     }
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const int b = c0 + 256 * c + 4 * lane;
-                        if (b < seg_bytes) { colbuf[b] = sum[c][0]; colbuf[b + 1] = sum[c][1]; colbuf[b + 2] = sum[c][2]; colbuf[b + 3] = sum[c][3]; }
+                    __builtin_amdgcn_wave_barrier();
+                    const float fkhA = (float)khA, fkhB = (float)khB;
+                    for (int idx = lane; idx < (oxb - oxa) * 3; idx += 64) {
+                        const int ox = oxa + idx / 3, c = idx % 3;
+                        const int xs = (ox * iw) / S, xe = ((ox + 1) * iw + S - 1) / S;
+                        unsigned accA = 0, accB = 0;
+                        for (int xx = xs; xx < xe; xx++) { accA += colA[(xx - xsa) * 3 + c]; accB += colB[(xx - xsa) * 3 + c]; }
+                        const float fkw = (float)(xe - xs);
+                        in_s[(oyA * S + ox) * 3 + c] = ((float)accA / fkhA / fkw - 127.5f) * 0.0078125f;
+                        in_s[(oyB * S + ox) * 3 + c] = ((float)accB / fkhB / fkw - 127.5f) * 0.0078125f;
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    oxa = oxb;
                 }
-                __builtin_amdgcn_wave_barrier();
-                for (int idx = lane; idx < (oxb - oxa) * 3; idx += 64) {
-                    const int ox = oxa + idx / 3, c = idx % 3;
-                    const int xs = (ox * iw) / S, xe = ((ox + 1) * iw + S - 1) / S;
-                    unsigned acc = 0;
-                    for (int xx = xs; xx < xe; xx++) acc += colbuf[(xx - xsa) * 3 + c];
-                    in_s[(oy * S + ox) * 3 + c] = ((float)acc / kh / (float)(xe - xs) - 127.5f) * 0.0078125f;
-                }
-                __builtin_amdgcn_wave_barrier();
-                oxa = oxb;
             }
         }
         for (int p = IN_N + tid; p < IN_N + 128; p += 256) in_s[p] = 0.f;   // read by the zero-weight k = 27 pad
@@ -174,6 +255,7 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
     float* dst = out + (size_t)blockIdx.x * P * P * C1;
     auto act = [&](float v, float sl) { return MODE == 2 ? fmaxf(v, sl * v) : (v > 0.f ? v : sl * v); };
     float* const erow = c1_s + (kq * 4) * CLD + l15;             // epilogue lane base: row 4*kq (+q), channel l15
+    if (dbg_skip & 2) return;
     for (int p0 = 0; p0 < P; p0 += R) {
         const int rows0 = 2 * p0;
         const int nrows = (CW - rows0) < SR ? (CW - rows0) : SR;
@@ -271,6 +353,9 @@ int slope_mode(const DevV* sl, int n) {
 
 }  // namespace
 
+// timing-only ablation (TRL_FRONT_SKIP: 1/2 = R-Net crop / conv+pool, 4/8 = O-Net); 0 in production
+static int front_dbg() { static const int v = getenv("TRL_FRONT_SKIP") ? atoi(getenv("TRL_FRONT_SKIP")) : 0; return v; }
+
 // R-Net front: pooled [nc][11][11][28]
 int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, int t0, int nc, float* d_pool,
                           hipStream_t s) {
@@ -280,7 +365,7 @@ int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("rnet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->rnet_front_mode < 0) c->rnet_front_mode = slope_mode(sl, 28);
 #define TRL_RF(MODE) k_mtcnn_front<24, 28, 4, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
-                                                                       c->cb.map_local, t0, w->p, b->p, sl->p, d_pool)
+                                                                       c->cb.map_local, t0, w->p, b->p, sl->p, d_pool, front_dbg() & 3)
     if (c->rnet_front_mode == 2) TRL_RF(2); else if (c->rnet_front_mode == 1) TRL_RF(1); else TRL_RF(0);
 #undef TRL_RF
     TRL_LAUNCH_CHECK();
@@ -295,7 +380,7 @@ int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("onet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->onet_front_mode < 0) c->onet_front_mode = slope_mode(sl, 32);
 #define TRL_OF(MODE) k_mtcnn_front<48, 32, 3, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
-                                                                       c->cb.map_local, t0, w->p, b->p, sl->p, d_pool)
+                                                                       c->cb.map_local, t0, w->p, b->p, sl->p, d_pool, (front_dbg() >> 2) & 3)
     if (c->onet_front_mode == 2) TRL_OF(2); else if (c->onet_front_mode == 1) TRL_OF(1); else TRL_OF(0);
 #undef TRL_OF
     TRL_LAUNCH_CHECK();
