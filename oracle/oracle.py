@@ -128,6 +128,12 @@ class Oracle:
         self.lib.orc_facenet(C.c_void_p(self.ctx), _p(x), n, H, W, _p(emb))
         return emb
 
+    def selftest_recip_div(self, kmax):
+        """Mismatches between the device's reciprocal division and IEEE division over all bins <= kmax x kmax."""
+        self.lib.orc_selftest_recip_div.restype = C.c_long
+        self.lib.orc_selftest_recip_div.argtypes = [C.c_int]
+        return int(self.lib.orc_selftest_recip_div(int(kmax)))
+
     def nv12_to_bgr(self, nv12, H, W):
         nv12 = np.ascontiguousarray(nv12, np.uint8)
         out = np.empty((H, W, 3), np.uint8)

@@ -1065,3 +1065,32 @@ void orc_nv12_to_bgr(const uint8_t* nv12, int H, int W, uint8_t* bgr) {
             o[2] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
         }
 }
+
+/* ---- self test backing a DEVICE-side shortcut (csrc/trl_pnet.hip:pyr_div) ---------------------------------
+ * The pyramid kernel divides by the bin height and width with q0 = RN(a r), e = fma(-b, q0, a), q = fma(e, r, q0),
+ * r = RN(1/b), instead of two IEEE divisions.  The oracle itself keeps the true divisions (orc_area_resample_norm);
+ * this routine checks, for every bin size kh, kw <= kmax and every possible byte sum s <= 255 kh kw, that both
+ * routes give bit-identical results.  Returns the number of mismatches (0 expected). */
+static inline float selftest_rdiv(float a, float b, float r) {
+    const float q0 = a * r;
+    const float e = fmaf(-b, q0, a);
+    return fmaf(e, r, q0);
+}
+long orc_selftest_recip_div(int kmax) {
+    long bad = 0;
+#pragma omp parallel for schedule(dynamic) reduction(+ : bad)
+    for (int kh = 1; kh <= kmax; kh++) {
+        const float fkh = (float)kh, rkh = 1.0f / fkh;
+        for (int kw = 1; kw <= kmax; kw++) {
+            const float fkw = (float)kw, rkw = 1.0f / fkw;
+            const long smax = 255L * kh * kw;
+            for (long s = 0; s <= smax; s++) {
+                const float a = (float)s;
+                const float t = a / fkh / fkw;
+                const float u = selftest_rdiv(selftest_rdiv(a, fkh, rkh), fkw, rkw);
+                if (t != u) bad++;   /* finite, non-negative: value equality is bit equality */
+            }
+        }
+    }
+    return bad;
+}

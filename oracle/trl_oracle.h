@@ -115,6 +115,10 @@ void  orc_crop_area_std(const uint8_t* img, int H, int W, int x0, int y0, int x1
 int   orc_detect_embed_mode(const orc_ctx*, const uint8_t* frames, int n, int H, int W, const orc_params*, int mode,
                             float* box_out, float* prob_out, int32_t* rect_out, uint8_t* valid_out, float* emb_out);
 
+/* exhaustive check of the device's reciprocal division against IEEE division for bins up to kmax x kmax
+ * (csrc/trl_pnet.hip:pyr_div); returns the number of mismatching (kh, kw, sum) triples */
+long  orc_selftest_recip_div(int kmax);
+
 /* one NV12 frame (H*W luma + H/2 x W interleaved UV) -> BGR, OpenCV integer BT.601 */
 void  orc_nv12_to_bgr(const uint8_t* nv12, int H, int W, uint8_t* bgr);
 

@@ -218,3 +218,10 @@ def test_nv12_to_bgr_known_values(oracle):
     u = np.repeat(np.repeat(uv[..., 0], 2, 0), 2, 1); v = np.repeat(np.repeat(uv[..., 1], 2, 0), 2, 1)
     ref = np.stack([1.164 * y + 2.018 * u, 1.164 * y - 0.813 * v - 0.391 * u, 1.164 * y + 1.596 * v], -1).clip(0, 255)
     assert np.abs(got - ref).max() <= 1.0
+
+
+def test_reciprocal_division_is_exact(oracle):
+    """The pyramid kernel divides bin sums by kh and kw through precomputed reciprocals + two fmas
+    (csrc/trl_pnet.hip:pyr_div, enabled for bins <= 96).  Every (kh, kw, sum) triple must reproduce the two
+    IEEE divisions of the reference expression bit for bit -- exhaustive, ~5.5e9 cases, a few seconds."""
+    assert oracle.selftest_recip_div(96) == 0

@@ -52,6 +52,11 @@ struct PLevel {
     int mode, nd, grshift;   // pyramid kernel path, re-aligned dwords per row (mode 0), log2 groups per row (mode 1)
     unsigned wmagic;         // ceil(2^32 / w): pixel / w by __umulhi
     unsigned txmagic;        // ceil(2^32 / tiles_x): tile decode stays on the scalar unit
+    int khA, kwA, khmax, kwmax;   // adaptive-pool bins of the level are khA or khA+1 rows (kwA / kwA+1 columns)
+    float rkh[2], rkw[2];    // RN(1/khA), RN(1/(khA+1)), same for kw: reciprocal division (see pyr_div)
+    int fastdiv;             // bin sizes small enough for the exhaustively verified reciprocal division
+    unsigned hmagic;         // ceil(2^32 / h); with wmagic: bin edges by multiply-high when 'arith' (no table load in the
+    int arith;               // dependent-latency chain of a pixel): requires H*h*h < 2^32 and W*w*w < 2^32
     float scale;
 };
 struct PnetArgs {
@@ -108,20 +113,49 @@ __device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF
     return (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
 }
 
+// The pyramid is written once and read once, much later, by the PNet kernel: stream it past the caches so the source
+// frame (re-read by every level) keeps its L2 / Infinity Cache lines.
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pyr_store(float4* dst, const float4& v) {
+    static_assert(sizeof(float4) == sizeof(f32x4_nt), "layout");
+    f32x4_nt t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4_nt*>(dst));
+}
+
+// Correctly rounded a / b from r = RN(1/b) (Markstein): q0 = RN(a r), e = a - b q0 (exact in one fma), q = RN(q0 + e r).
+// For a = integer sums up to 255 kh kw and the bin sizes used here (kh, kw <= 96) the result equals the IEEE
+// quotient for EVERY input -- checked exhaustively by the oracle's self test (oracle/trl_oracle.c:orc_selftest_recip_div);
+// larger bins take the true division.  3 VALU ops instead of the ~11 of v_div_scale/v_rcp/v_div_fmas/v_div_fixup.
+__device__ __forceinline__ float pyr_div(float a, float b, float r) {
+    const float q0 = a * r;
+    const float e = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(e, r, q0);
+}
+__device__ __forceinline__ float pyr_norm(unsigned s, int kh, int kw, const PLevel& g) {
+    const float a = (float)s, fkh = (float)kh, fkw = (float)kw;
+    float q;
+    if (g.fastdiv) {
+        const float r1 = kh == g.khA ? g.rkh[0] : g.rkh[1], r2 = kw == g.kwA ? g.rkw[0] : g.rkw[1];
+        q = pyr_div(pyr_div(a, fkh, r1), fkw, r2);
+    } else {
+        q = a / fkh / fkw;
+    }
+    return (q - 127.5f) * 0.0078125f;
+}
+
 struct PyrArgs { int H, W, n_frames, f0; long long pyr_stride; PLevel g; };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ frames, PyrArgs a, const uint32_t* __restrict__ tab,
-                                                 float4* __restrict__ pyr) {
-    const PLevel& g = a.g;                                  // one launch per level: every field is a kernel argument (SGPRs)
+// threads q = q0, q0 + qstep, ... of level g of frame f
+template <int MODE, typename A>
+__device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ frames, const A& a, const PLevel& g, const uint32_t* __restrict__ tab,
+                                          float4* __restrict__ pyr, int f, int q0, int qstep) {
     const int per_frame = g.pix_pad << g.gshift;            // threads of this level per frame
     constexpr int mode = MODE;
-    const int f = a.f0 + blockIdx.y;
     const uint32_t* base32 = reinterpret_cast<const uint32_t*>(frames);
     const long long fbase = (long long)f * a.H * a.W * 3;
     const long long last_dw = ((long long)a.n_frames * a.H * a.W * 3 - 1) >> 2;
     const int row_bytes = a.W * 3;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < per_frame; q += gridDim.x * blockDim.x) {
+    for (int q = q0; q < per_frame; q += qstep) {
         const int w = g.w, gsh = g.gshift, G = 1 << gsh;
         const int pixel = q >> gsh, sub = q & (G - 1);
         const bool valid = pixel < g.h * w;
@@ -233,15 +267,108 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ fra
             s0 += __shfl_xor((int)s0, off, 64); s1 += __shfl_xor((int)s1, off, 64); s2 += __shfl_xor((int)s2, off, 64);
         }
         if (sub == 0 && pixel < g.pix_pad) {
-            const float fkh = (float)kh, fkw = (float)kw;
             float4 o4;
-            o4.x = valid ? ((float)s0 / fkh / fkw - 127.5f) * 0.0078125f : 0.f;
-            o4.y = valid ? ((float)s1 / fkh / fkw - 127.5f) * 0.0078125f : 0.f;
-            o4.z = valid ? ((float)s2 / fkh / fkw - 127.5f) * 0.0078125f : 0.f;
+            o4.x = valid ? pyr_norm(s0, kh, kw, g) : 0.f;
+            o4.y = valid ? pyr_norm(s1, kh, kw, g) : 0.f;
+            o4.z = valid ? pyr_norm(s2, kh, kw, g) : 0.f;
             o4.w = 0.f;
-            pyr[(long long)f * a.pyr_stride + g.pix0 + pixel] = o4;
+            pyr_store(pyr + ((long long)f * a.pyr_stride + g.pix0 + pixel), o4);
         }
     }
+}
+
+// Mode 0 (bins <= 5 px wide and <= 5 rows: the three finest levels = 85 % of the output pixels): one lane per pixel.
+// VALU-bound, so everything per-row is pared down: the frame base is a scalar, the lane offset 32-bit; rows are
+// unrolled to the level's khmax (scalar) and only the last one can be dead; the byte masks of the two possible bin
+// widths are picked, not computed.
+template <typename A>
+__device__ __forceinline__ void pyr_level0(const uint8_t* __restrict__ frames, const A& a, const PLevel& g, const uint32_t* __restrict__ tab,
+                                           float4* __restrict__ pyr, int f, int q0, int qstep) {
+    const long long fbase = (long long)f * a.H * a.W * 3;
+    const long long total = (long long)a.n_frames * a.H * a.W * 3;
+    const int fb3 = (int)(fbase & 3);
+    const char* fptr = reinterpret_cast<const char*>(frames) + (fbase - fb3);     // dword aligned, scalar
+    const int row_bytes = a.W * 3;
+    const bool four = g.nd > 3;
+    const unsigned ndw = four ? 5 : 4;                                               // dwords fetched per row
+    const bool lastf = f == a.n_frames - 1;                                          // other frames may read into their successor
+    const unsigned avail = ((unsigned)fb3 + (unsigned)a.H * row_bytes + 3u) & ~3u;  // bytes from fptr to the end of the last dword
+    for (int pixel = q0; pixel < g.pix_pad; pixel += qstep) {
+        const bool valid = pixel < g.h * g.w;
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            const int oy = (int)__umulhi((unsigned)pixel, g.wmagic), ox = pixel - oy * g.w;
+            int ys, kh, xs, kw;
+            if (g.arith) {   // adaptive_avg_pool2d edges [floor(i*in/out), ceil((i+1)*in/out)) without touching memory
+                ys = (int)__umulhi((unsigned)(oy * a.H), g.hmagic);
+                kh = (int)__umulhi((unsigned)((oy + 1) * a.H + g.h - 1), g.hmagic) - ys;
+                xs = (int)__umulhi((unsigned)(ox * a.W), g.wmagic);
+                kw = (int)__umulhi((unsigned)((ox + 1) * a.W + g.w - 1), g.wmagic) - xs;
+            } else {
+                const uint32_t ty = tab[g.ytab0 + oy], tx = tab[g.xtab0 + ox];
+                ys = ty & 0xFFFF; kh = (int)(ty >> 16) - ys; xs = tx & 0xFFFF; kw = (int)(tx >> 16) - xs;
+            }
+            const int nbytes = kw * 3;
+            const unsigned lo0 = (unsigned)(ys * row_bytes + xs * 3 + fb3);        // byte offset from fptr of the bin's first byte
+            const unsigned vm0 = valid_bytes(0, nbytes), vm1 = valid_bytes(4, nbytes), vm2 = valid_bytes(8, nbytes),
+                           vm3 = valid_bytes(12, nbytes);
+            // the aligned 16/20-byte fetch of the LAST row may run past the end of the frame buffer only for the very
+            // last pixels of the last frame: those take per-dword clamped loads
+            const bool safe = !lastf || (lo0 & ~3u) + (unsigned)((kh - 1) * row_bytes) + 4u * ndw <= avail;
+            unsigned s0 = 0, s1 = 0, s2 = 0;
+            unsigned ww[5][5], shv[5];
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                if (r < g.khmax) {
+                    const unsigned lo = lo0 + (unsigned)((r < kh ? r : kh - 1) * row_bytes);
+                    shv[r] = lo & 3u;
+                    const char* p = fptr + (lo & ~3u);
+                    if (safe) {
+                        const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(p);
+                        ww[r][0] = v4[0]; ww[r][1] = v4[1]; ww[r][2] = v4[2]; ww[r][3] = v4[3];
+                        ww[r][4] = four ? *reinterpret_cast<const uint32_t*>(p + 16) : 0u;
+                    } else {
+                        const long long lim = ((total - 1) >> 2) * 4 - (fbase - fb3);   // offset of the last dword holding frame bytes
+#pragma unroll
+                        for (int j = 0; j < 5; j++) {
+                            const long long o = (long long)(lo & ~3u) + 4 * j;
+                            ww[r][j] = *reinterpret_cast<const uint32_t*>(fptr + (o < lim ? o : lim));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                if (r < g.khmax) {
+                    const bool act = r < kh;                                     // only the last unrolled row can be dead
+                    const unsigned sh = shv[r];
+                    const unsigned d0 = __builtin_amdgcn_alignbyte(ww[r][1], ww[r][0], sh) & (act ? vm0 : 0u);
+                    const unsigned d1 = __builtin_amdgcn_alignbyte(ww[r][2], ww[r][1], sh) & (act ? vm1 : 0u);
+                    const unsigned d2 = __builtin_amdgcn_alignbyte(ww[r][3], ww[r][2], sh) & (act ? vm2 : 0u);
+                    s0 = __builtin_amdgcn_udot4(d0, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d0, 0x00000100u, s1, false);
+                    s2 = __builtin_amdgcn_udot4(d0, 0x00010000u, s2, false);
+                    s0 = __builtin_amdgcn_udot4(d1, 0x00010000u, s0, false); s1 = __builtin_amdgcn_udot4(d1, 0x01000001u, s1, false);
+                    s2 = __builtin_amdgcn_udot4(d1, 0x00000100u, s2, false);
+                    s0 = __builtin_amdgcn_udot4(d2, 0x00000100u, s0, false); s1 = __builtin_amdgcn_udot4(d2, 0x00010000u, s1, false);
+                    s2 = __builtin_amdgcn_udot4(d2, 0x01000001u, s2, false);
+                    if (four) {
+                        const unsigned d3 = __builtin_amdgcn_alignbyte(ww[r][4], ww[r][3], sh) & (act ? vm3 : 0u);
+                        s0 = __builtin_amdgcn_udot4(d3, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d3, 0x00000100u, s1, false);
+                        s2 = __builtin_amdgcn_udot4(d3, 0x00010000u, s2, false);
+                    }
+                }
+            }
+            o4.x = pyr_norm(s0, kh, kw, g); o4.y = pyr_norm(s1, kh, kw, g); o4.z = pyr_norm(s2, kh, kw, g);
+        }
+        pyr_store(pyr + ((long long)f * a.pyr_stride + g.pix0 + pixel), o4);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ frames, PyrArgs a, const uint32_t* __restrict__ tab,
+                                                 float4* __restrict__ pyr) {
+    if (MODE == 0) pyr_level0(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    else pyr_level<MODE>(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ---- fused PNet --------------------------------------------------------------------------------------
@@ -645,10 +772,19 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
         p.pix_pad = (int)(((long long)g.h * g.w + 63) & ~63ll);
         pix += p.pix_pad;
         // pyramid kernel path and lanes per output pixel
-        const int khmax = (H + g.h - 1) / g.h + 1, kwmax = (W + g.w - 1) / g.w + 1;
+        const int khmax = (H + g.h - 1) / g.h + 1, kwmax = (W + g.w - 1) / g.w + 1;   // upper bounds of the bin sizes
+        p.khA = (H + g.h - 1) / g.h; p.kwA = (W + g.w - 1) / g.w;
+        p.khmax = (H % g.h) ? p.khA + 1 : p.khA; p.kwmax = (W % g.w) ? p.kwA + 1 : p.kwA;
+        p.rkh[0] = 1.0f / (float)p.khA; p.rkh[1] = 1.0f / (float)(p.khA + 1);
+        p.rkw[0] = 1.0f / (float)p.kwA; p.rkw[1] = 1.0f / (float)(p.kwA + 1);
+        p.fastdiv = (p.khA + 1 <= 96 && p.kwA + 1 <= 96) ? 1 : 0;
         p.wmagic = (unsigned)((0x100000000ull + g.w - 1) / g.w);
+        p.hmagic = (unsigned)((0x100000000ull + g.h - 1) / g.h);
+        // floor(n / d) == umulhi(n, ceil(2^32 / d)) for every n with n * d < 2^32 (n <= (in + 1) * out here)
+        p.arith = ((unsigned long long)(H + 1) * g.h * g.h < 0x100000000ull && (unsigned long long)(W + 1) * g.w * g.w < 0x100000000ull &&
+                   g.h > 1 && g.w > 1) ? 1 : 0;
         p.nd = 3; p.grshift = 0;
-        if (kwmax * 3 <= 15) {
+        if (kwmax * 3 <= 15 && khmax <= 5) {
             p.mode = 0; p.gshift = 0; p.nd = kwmax * 3 <= 9 ? 3 : 4;
         } else if ((W * 3) % 4 == 0) {
             p.mode = 1;
