@@ -14,6 +14,7 @@
 //               ds_read_b32 operand reads are conflict-free (32 consecutive floats per half-wave).
 //               Next chunk's global loads are issued before the MFMAs of the current chunk.
 #include "trl_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -320,9 +321,172 @@ __global__ __launch_bounds__(256) void conv_splitk4(ConvArgs a) {
     }
 }
 
+// conv_tap: the same implicit GEMM for layers whose K chunks never straddle a filter tap (Cin % BK == 0): the
+// im2col cursor (ky, kx, c0) of a chunk is then UNIFORM and lives on the scalar unit, a thread's gather address is
+// one 32-bit per-thread offset plus that scalar, rows past M re-read row 0 (their results are never stored) and the
+// weight matrix is addressed the same way.  The K loop of conv_igemm spends ~160 VALU instructions per chunk on
+// per-slot cursors and bounds tests; f32 MFMA and VALU share the FP32 pipe on gfx950, so that was ~30 % of the
+// loop.  Here it is ~20.  Same k order, same bias-seeded chain: bit-identical results.
+// PAD = the layer has spatial padding (taps falling outside the image load nothing and contribute zeros).
+template <int BM, int BN, int WM, int WN, int BK, bool PAD>
+__global__ __launch_bounds__(256) void conv_tap(ConvArgs a) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int KG = BK / 4;                                   // float4 groups along k per chunk
+    constexpr int ASLOTS = BM * KG, APT = (ASLOTS + 255) / 256;
+    constexpr int BSLOTS = BK * (BN / 4), BPT = (BSLOTS + 255) / 256;
+    constexpr int GSTEP = 256 / BM;                              // k-group stride between a thread's A slots
+    static_assert(WM * WN == 4 && 256 % BM == 0 && BK % 4 == 0 && BK % 2 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) float As[BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- per-thread A row: element offset of (image, iy0, ix0, channel 4*g0) from a.x ---------------------
+    const int row = tid % BM, g0 = tid / BM;
+    const int m = m0 + row;
+    const int mm = m < a.M ? m : 0;
+    const int ohw = a.OH * a.OW;
+    const int nimg = mm / ohw;
+    const int rem = mm - nimg * ohw;
+    const int oy = rem / a.OW, ox = rem - oy * a.OW;
+    const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
+    const int aoff = ((nimg * a.H + iy0) * a.W + ix0) * a.ldx + a.xoff + 4 * g0;      // < 2^31: checked by the launcher
+    // ---- per-thread B slot: (k row kk0, column n) ------------------------------------------------------------
+    const int bkk = tid / (BN / 4), bn4 = tid % (BN / 4);
+    int bn = n0 + 4 * bn4;
+    bn = bn < a.ldw ? bn : 0;                                   // columns past the matrix re-read column 0 (never stored)
+    const int boff = bkk * a.ldw + bn;
+    constexpr int BKSTEP = 256 / (BN / 4);                       // k-row stride between a thread's B slots
+
+    float4 areg[APT];
+    float4 breg[BPT];
+    int ky = 0, kx = 0, c0 = 0;                                 // scalar cursor of the NEXT chunk to load
+    int k0 = 0;
+    auto load_chunk = [&]() {
+        const int soff = (ky * a.W + kx) * a.ldx + c0;         // scalar
+        bool inside = true;
+        if (PAD) inside = (unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W;
+#pragma unroll
+        for (int i = 0; i < APT; i++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((ASLOTS % 256 == 0 || tid + i * 256 < ASLOTS) && inside)
+                v = *reinterpret_cast<const float4*>(a.x + (aoff + soff + 4 * GSTEP * i));
+            areg[i] = v;
+        }
+        const float* wrow = a.w + (size_t)k0 * a.ldw;           // scalar
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BSLOTS % 256 == 0 || tid + i * 256 < BSLOTS) v = *reinterpret_cast<const float4*>(wrow + (boff + BKSTEP * i * a.ldw));
+            breg[i] = v;
+        }
+        // advance: next BK channels of the tap, else next tap
+        k0 += BK; c0 += BK;
+        if (c0 >= a.Cin) { c0 = 0; if (++kx == a.KW) { kx = 0; ++ky; } }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < APT; i++) {
+            if (ASLOTS % 256 == 0 || tid + i * 256 < ASLOTS) {
+                const int g = g0 + GSTEP * i;
+                As[(4 * g + 0) * BM + row] = areg[i].x;
+                As[(4 * g + 1) * BM + row] = areg[i].y;
+                As[(4 * g + 2) * BM + row] = areg[i].z;
+                As[(4 * g + 3) * BM + row] = areg[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            if (BSLOTS % 256 == 0 || tid + i * 256 < BSLOTS)
+                *reinterpret_cast<float4*>(&Bs[(bkk + BKSTEP * i) * BN + 4 * bn4]) = breg[i];
+        }
+    };
+
+    // ---- accumulators start at the bias (chain head) ---------------------------------------
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        const int n = n0 + (wn * TN + tn) * 32 + r;
+        const float b = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[tm][tn][i] = b;
+    }
+
+    const int nchunks = a.K / BK;
+    load_chunk();
+    for (int ch = 0; ch < nchunks; ch++) {
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk();
+#pragma unroll
+        for (int s = 0; s < BK / 2; s++) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) av[tm] = As[(2 * s + h) * BM + (wm * TM + tm) * 32 + r];
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) bv[tn] = Bs[(2 * s + h) * BN + (wn * TN + tn) * 32 + r];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (as conv_igemm) --------------------------------------------------------------------------------
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        const int n = n0 + (wn * TN + tn) * 32 + r;
+        if (n >= a.Cout) continue;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        const float sf = a.scale ? a.shift[n] : 0.f;
+        const float sl = a.act == TRL_ACT_PRELU ? a.slope[n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int mr = m0 + (wm * TM + tm) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (mr >= a.M) continue;
+                float v = acc[tm][tn][i];
+                if (a.scale) v = __builtin_fmaf(v, sc, sf);
+                if (a.res) {
+                    v = v * a.res_scale;
+                    v = v + a.res[(size_t)mr * a.ldres + n];
+                }
+                if (a.act == TRL_ACT_RELU) v = v > 0.f ? v : 0.f;
+                else if (a.act == TRL_ACT_PRELU) v = v > 0.f ? v : sl * v;
+                a.y[(size_t)mr * a.ldy + a.yoff + n] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
+int launch_tap(const ConvArgs& a, dim3 grid, hipStream_t s) {
+    if (a.ph || a.pw) conv_tap<BM, BN, WM, WN, BK, true><<<grid, 256, 0, s>>>(a);
+    else conv_tap<BM, BN, WM, WN, BK, false><<<grid, 256, 0, s>>>(a);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 int launch_cfg(const ConvArgs& a, bool vec, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
+    // whole-tap chunks (conv_tap) whenever the channel count allows it and 32-bit element offsets suffice
+    static const bool tap_off = getenv("TRL_NO_TAP") != nullptr;
+    const long long x_elems = (long long)a.N * a.H * a.W * a.ldx + a.xoff;
+    if (vec && !tap_off && a.K == a.KH * a.KW * a.Cin && x_elems < 0x7fffffffll && (long long)a.K * a.ldw < 0x7fffffffll) {
+        if (BK >= 64 && a.Cin % 64 == 0) return launch_tap<BM, BN, WM, WN, 64>(a, grid, s);
+        if (a.Cin % 32 == 0) return launch_tap<BM, BN, WM, WN, 32>(a, grid, s);
+        if (BM == 128 && BN == 64 && a.Cin % 28 == 0) return launch_tap<BM, BN, WM, WN, 28>(a, grid, s);
+        if (a.Cin % 16 == 0) return launch_tap<BM, BN, WM, WN, 16>(a, grid, s);
+    }
     if (vec) conv_igemm<BM, BN, WM, WN, BK, true><<<grid, 256, 0, s>>>(a);
     else conv_igemm<BM, BN, WM, WN, 16, false><<<grid, 256, 0, s>>>(a);
     TRL_LAUNCH_CHECK();
