@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -289,6 +290,111 @@ __global__ __launch_bounds__(256) void conv_splitk4(ConvArgs a) {
         if (k0 + BK < ke) load_chunk(k0 + BK);
 #pragma unroll
         for (int s = 0; s < BK / 2; s++) {
+            const float av = Aw[(2 * s + h) * BM + r];
+            const float b0 = Bw[(2 * s + h) * BN + r], b1 = Bw[(2 * s + h) * BN + 32 + r];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* red = &Bs[0][0];                              // [wave][tn][reg][lane]
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) red[((wave * 2 + tn) * 16 + i) * 64 + lane] = acc[tn][i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int e = tid + 256 * j;
+        const int tn = e >> 10, reg = (e >> 6) & 15, ln = e & 63;
+        const int mr = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
+        const int n = n0 + tn * 32 + (ln & 31);
+        if (mr >= a.M || n >= a.Cout) continue;
+        float v = (red[e] + red[2048 + e]) + (red[4096 + e] + red[6144 + e]);
+        if (a.scale) v = __builtin_fmaf(v, a.scale[n], a.shift[n]);
+        if (a.res) {
+            v = v * a.res_scale;
+            v = v + a.res[(size_t)mr * a.ldres + n];
+        }
+        if (a.act == TRL_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (a.act == TRL_ACT_PRELU) v = v > 0.f ? v : a.slope[n] * v;
+        a.y[(size_t)mr * a.ldy + a.yoff + n] = v;
+    }
+}
+
+// conv_splitk4_tap: conv_splitk4 with whole-tap chunks (Cin % BKC == 0 and (K/4) % BKC == 0): the im2col cursor of a
+// wave's quarter is a scalar, gather addresses are a per-lane 32-bit offset plus that scalar (see conv_tap).
+template <int BKC, bool PAD>
+__global__ __launch_bounds__(256) void conv_splitk4_tap(ConvArgs a) {
+    constexpr int BM = 32, BN = 64;
+    constexpr int AS = BKC / 8, BSL = BKC / 4;                        // float4 slots per lane: A (rows x k-groups), B
+    __shared__ __attribute__((aligned(16))) float As[4][BKC * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[4][32 * BN];     // staging uses BKC rows; later the 4 x (32x64) partial tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int segK = a.K >> 2, ks = wave * segK;
+
+    const int m = m0 + r;
+    const int mm = m < a.M ? m : 0;
+    const int ohw = a.OH * a.OW;
+    const int nimg = mm / ohw;
+    const int rem = mm - nimg * ohw;
+    const int oy = rem / a.OW, ox = rem - oy * a.OW;
+    const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
+    const int aoff = ((nimg * a.H + iy0) * a.W + ix0) * a.ldx + a.xoff + 4 * h;
+    int bn = n0 + 4 * (lane & 15);
+    bn = bn < a.ldw ? bn : 0;
+    const int boff = (lane >> 4) * a.ldw + bn;
+
+    // scalar cursor of the wave's quarter
+    const int tap0 = ks / a.Cin;
+    int c0 = ks - tap0 * a.Cin, ky = tap0 / a.KW, kx = tap0 - ky * a.KW, k0 = ks;
+    f32x4s areg[AS], breg[BSL];
+    auto load_chunk = [&]() __attribute__((always_inline)) {
+        const int soff = (ky * a.W + kx) * a.ldx + c0;
+        bool inside = true;
+        if (PAD) inside = (unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W;
+#pragma unroll
+        for (int i = 0; i < AS; i++) {
+            f32x4s v = {0.f, 0.f, 0.f, 0.f};
+            if (inside) v = *reinterpret_cast<const f32x4s*>(a.x + (aoff + soff + 8 * i));
+            areg[i] = v;
+        }
+        const float* wrow = a.w + (size_t)k0 * a.ldw;
+#pragma unroll
+        for (int i = 0; i < BSL; i++) breg[i] = *reinterpret_cast<const f32x4s*>(wrow + (boff + 4 * i * a.ldw));
+        k0 += BKC; c0 += BKC;
+        if (c0 >= a.Cin) { c0 = 0; if (++kx == a.KW) { kx = 0; ++ky; } }
+    };
+    float* Aw = As[wave];
+    float* Bw = Bs[wave];
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < AS; i++) {
+            const int g = h + 2 * i;
+            Aw[(4 * g + 0) * BM + r] = areg[i][0]; Aw[(4 * g + 1) * BM + r] = areg[i][1];
+            Aw[(4 * g + 2) * BM + r] = areg[i][2]; Aw[(4 * g + 3) * BM + r] = areg[i][3];
+        }
+#pragma unroll
+        for (int i = 0; i < BSL; i++) *reinterpret_cast<f32x4s*>(&Bw[((lane >> 4) + 4 * i) * BN + 4 * (lane & 15)]) = breg[i];
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        const int n = n0 + tn * 32 + r;
+        const float b = (wave == 0 && a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;   // chain 0 starts at the bias
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[tn][i] = b;
+    }
+    const int nchunks = segK / BKC;
+    load_chunk();
+    for (int ch = 0; ch < nchunks; ch++) {
+        store_chunk();                                   // wave-private staging: LDS ops of one wave stay in order
+        if (ch + 1 < nchunks) load_chunk();
+#pragma unroll
+        for (int s = 0; s < BKC / 2; s++) {
             const float av = Aw[(2 * s + h) * BM + r];
             const float b0 = Bw[(2 * s + h) * BN + r], b1 = Bw[(2 * s + h) * BN + 32 + r];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
@@ -638,7 +744,17 @@ int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
     if (a.OH * a.OW <= 9 && a.K >= 512 && (a.K & 15) == 0) {
         if (!vec) { trl_set_error("split-K layer needs Cin %% 4 == 0 and 16-byte aligned input"); return TRL_ERR_INVALID; }
         dim3 grid((a.M + 31) / 32, (a.Cout + 63) / 64);
-        conv_splitk4<<<grid, 256, 0, s>>>(a);
+        static const bool tap_off = getenv("TRL_NO_TAP") != nullptr;
+        const int segK = a.K >> 2;
+        const bool small = (long long)a.N * a.H * a.W * a.ldx + a.xoff < 0x7fffffffll && (long long)a.K * a.ldw < 0x7fffffffll;
+        const bool pad = a.ph || a.pw;
+        if (!tap_off && small && a.K == a.KH * a.KW * a.Cin && a.Cin % 32 == 0 && segK % 32 == 0) {
+            if (pad) conv_splitk4_tap<32, true><<<grid, 256, 0, s>>>(a); else conv_splitk4_tap<32, false><<<grid, 256, 0, s>>>(a);
+        } else if (!tap_off && small && a.K == a.KH * a.KW * a.Cin && a.Cin % 16 == 0 && segK % 16 == 0) {
+            if (pad) conv_splitk4_tap<16, true><<<grid, 256, 0, s>>>(a); else conv_splitk4_tap<16, false><<<grid, 256, 0, s>>>(a);
+        } else {
+            conv_splitk4<<<grid, 256, 0, s>>>(a);
+        }
         TRL_LAUNCH_CHECK();
         return TRL_OK;
     }
