@@ -168,48 +168,7 @@ __device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ frames, co
             kh = ye - ys; kw = xe - xs;
             const int nbytes = kw * 3;
             const long long o0 = fbase + (long long)ys * row_bytes + xs * 3;   // first byte of the bin
-            if (mode == 0) {
-                const unsigned vm0 = valid_bytes(0, nbytes), vm1 = valid_bytes(4, nbytes), vm2 = valid_bytes(8, nbytes),
-                               vm3 = valid_bytes(12, nbytes);
-                const bool four = g.nd > 3;
-                // rows in batches of 4: all loads of a batch are in flight before any is consumed (one latency, not kh)
-                for (int y0 = 0; y0 < kh; y0 += 4) {
-                    unsigned ww[4][5];
-                    unsigned shv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int y = (y0 + r < kh) ? y0 + r : kh - 1;
-                        const long long o = o0 + (long long)y * row_bytes;
-                        const long long dw = o >> 2;
-                        shv[r] = (unsigned)(o & 3);
-                        if (dw + 4 <= last_dw) {   // dword-aligned 16-byte load (+1 dword when bins reach 5 px)
-                            const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(base32 + dw);
-                            ww[r][0] = v4[0]; ww[r][1] = v4[1]; ww[r][2] = v4[2]; ww[r][3] = v4[3];
-                            ww[r][4] = four ? base32[dw + 4] : 0u;
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 5; j++) ww[r][j] = base32[dw + j <= last_dw ? dw + j : last_dw];
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const bool act = y0 + r < kh;
-                        const unsigned sh = shv[r];
-                        const unsigned d0 = __builtin_amdgcn_alignbyte(ww[r][1], ww[r][0], sh) & (act ? vm0 : 0u);
-                        const unsigned d1 = __builtin_amdgcn_alignbyte(ww[r][2], ww[r][1], sh) & (act ? vm1 : 0u);
-                        const unsigned d2 = __builtin_amdgcn_alignbyte(ww[r][3], ww[r][2], sh) & (act ? vm2 : 0u);
-                        const unsigned d3 = __builtin_amdgcn_alignbyte(ww[r][4], ww[r][3], sh) & ((act && four) ? vm3 : 0u);
-                        s0 = __builtin_amdgcn_udot4(d0, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d0, 0x00000100u, s1, false);
-                        s2 = __builtin_amdgcn_udot4(d0, 0x00010000u, s2, false);
-                        s0 = __builtin_amdgcn_udot4(d1, 0x00010000u, s0, false); s1 = __builtin_amdgcn_udot4(d1, 0x01000001u, s1, false);
-                        s2 = __builtin_amdgcn_udot4(d1, 0x00000100u, s2, false);
-                        s0 = __builtin_amdgcn_udot4(d2, 0x00000100u, s0, false); s1 = __builtin_amdgcn_udot4(d2, 0x00010000u, s1, false);
-                        s2 = __builtin_amdgcn_udot4(d2, 0x01000001u, s2, false);
-                        s0 = __builtin_amdgcn_udot4(d3, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d3, 0x00000100u, s1, false);
-                        s2 = __builtin_amdgcn_udot4(d3, 0x00010000u, s2, false);
-                    }
-                }
-            } else if (mode == 1) {
+            if (mode == 1) {
                 const int grsh = g.grshift, grp = sub & ((1 << grsh) - 1), rlane = sub >> grsh, rl = G >> grsh;
                 const int sh = (int)(o0 & 3);
                 const int rel = -sh + 12 * grp;                      // offset of this lane's group relative to the bin's first byte
