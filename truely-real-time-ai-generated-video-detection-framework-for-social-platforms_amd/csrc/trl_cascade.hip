@@ -313,34 +313,6 @@ __global__ void k_build_map(const int32_t* __restrict__ cnt, const int32_t* __re
     for (int i = threadIdx.x; i < c; i += blockDim.x) { map_frame[o + i] = f; map_local[o + i] = i; }
 }
 
-// crop [y-1:ey, x-1:ex] + imresample to SxS + normalise, one workgroup per candidate
-__global__ __launch_bounds__(256) void k_crop_resample(const uint8_t* __restrict__ frames, int H, int W, int S_, int capF,
-                                                       const float* __restrict__ boxes, const int32_t* __restrict__ map_frame,
-                                                       const int32_t* __restrict__ map_local, int t0, float* __restrict__ out) {
-    const int t = t0 + blockIdx.x;
-    const int f = map_frame[t], i = map_local[t];
-    const float* b = boxes + ((size_t)f * capF + i) * 5;
-    int y, ey, x, ex;
-    pad1(b[0], b[1], b[2], b[3], W, H, y, ey, x, ex);
-    const int y0 = y - 1, x0 = x - 1, ih = ey - y0, iw = ex - x0;
-    const uint8_t* fp = frames + (size_t)f * H * W * 3;
-    float* o = out + (size_t)blockIdx.x * S_ * S_ * 3;
-    for (int p = threadIdx.x; p < S_ * S_; p += blockDim.x) {
-        const int oy = p / S_, ox = p - oy * S_;
-        const int ys = (oy * ih) / S_, ye = ((oy + 1) * ih + S_ - 1) / S_;
-        const int xs = (ox * iw) / S_, xe = ((ox + 1) * iw + S_ - 1) / S_;
-        unsigned s0 = 0, s1 = 0, s2 = 0;
-        for (int yy = ys; yy < ye; yy++) {
-            const uint8_t* q = fp + ((size_t)(y0 + yy) * W + x0 + xs) * 3;
-            for (int xx = xs; xx < xe; xx++, q += 3) { s0 += q[0]; s1 += q[1]; s2 += q[2]; }
-        }
-        const float kh = (float)(ye - ys), kw = (float)(xe - xs);
-        o[3 * p + 0] = ((float)s0 / kh / kw - 127.5f) * 0.0078125f;
-        o[3 * p + 1] = ((float)s1 / kh / kw - 127.5f) * 0.0078125f;
-        o[3 * p + 2] = ((float)s2 / kh / kw - 127.5f) * 0.0078125f;
-    }
-}
-
 // ---- stage 2 tail: thr1, batched_nms(0.7), bbreg, rerec ------------------------------------------
 __global__ __launch_bounds__(256) void k_stage2_post(int capF, int W, int H, float thr, const int32_t* __restrict__ n1,
                                                      const float* __restrict__ s1_box, const int32_t* __restrict__ off2,
