@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 2
+#define TRL_ABI_VERSION 3
 
 typedef enum {
     TRL_OK = 0,
@@ -56,6 +56,10 @@ typedef struct {
     int    embed_mode;      /* 0 = reference: 80x80 INTER_LINEAR crop, BGR, /255 (model.py:41,57-58)  [default]
                              * 1 = SURVEY 8(f)-4 native mode: facenet-pytorch extract_face (160x160 area
                              *     resample, .byte(), (x-127.5)/128), channel order kept; 2 = same, BGR->RGB */
+    int    embed_precision; /* 0 = f32, bit-exact with the oracle                                        [default]
+                             * 1 = bf16 activations/weights on the bf16 matrix cores for InceptionResnetV1 only
+                             *     (BASELINE configs[2]); detector, crops and valid mask stay f32-exact; embeddings
+                             *     agree with the f32 path to ~1e-2 (cosine > 0.999), see tests/test_gpu_api.py */
 } trl_config;
 
 int  trl_abi_version(void);
@@ -116,6 +120,8 @@ int  trl_ingest_nv12(trl_ctx* ctx, const uint8_t* d_nv12, int n_in, int H, int W
 int  trl_debug_stage_boxes(trl_ctx* ctx, int stage, int frame, float* h_boxes, int max_rows, int* n_out);
 /* Per-level PNet candidate / kept counts of one frame (host output, up to 32 levels each). */
 int  trl_debug_level_counts(trl_ctx* ctx, int frame, int32_t* h_cand, int32_t* h_keep, int* n_levels);
+/* test hook: fill the activation workspaces with a byte pattern (0xFF -> NaNs) before the next call */
+int  trl_debug_poison(trl_ctx* ctx, int byte);
 /* PNet on one pyramid level of frame 0: face-prob map and regression map (device outputs). */
 int  trl_debug_pnet_level(trl_ctx* ctx, const uint8_t* d_frame, int H, int W, int level,
                           float* d_prob, float* d_reg, int* oh, int* ow, void* stream);

@@ -168,3 +168,16 @@ def test_drift_score_matches_oracle(engine, oracle):
     assert got["score"] == ref["score"] and got["run"] == ref["run"] and got["hits"] == ref["hits"]
     assert np.array_equal(got["sims"].cpu().numpy(), ref["sims"])
     assert np.array_equal(got["flags"].cpu().numpy(), ref["flags"])
+
+
+@pytest.mark.parametrize("byte", [0xFF, 0x7F])
+def test_results_do_not_depend_on_stale_memory(engine, oracle, byte):
+    """Workspaces AND the LDS of every CU are filled with NaN (0xFF) / huge-float (0x7F) patterns before the call:
+    a kernel that lets an uninitialised word reach an MFMA operand (even against a zero weight: NaN * 0 = NaN)
+    or a pooling window shows up here.  Regression test for the O-Net front kernel's k = 27 zero tail."""
+    for fr in (frames_small(6, 180, 320), truely_amd.synthetic.synthetic_frames(3, 720, 1280, seed=0)):
+        engine.poison_workspaces(byte)
+        out = engine.detect_embed(fr)
+        ref = oracle.detect_embed(fr)
+        for k in ("box", "prob", "rect", "valid", "emb"):
+            assert np.array_equal(out[k].cpu().numpy(), ref[k]), k

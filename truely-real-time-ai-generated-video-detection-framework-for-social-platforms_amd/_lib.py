@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libtruely_hip.so")
 class TrlConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("min_face_size", C.c_int), ("thr0", C.c_float), ("thr1", C.c_float),
                 ("thr2", C.c_float), ("factor", C.c_double), ("cap_level", C.c_int), ("cap_frame", C.c_int),
-                ("max_faces", C.c_int), ("pnet_mode", C.c_int), ("embed_mode", C.c_int)]
+                ("max_faces", C.c_int), ("pnet_mode", C.c_int), ("embed_mode", C.c_int), ("embed_precision", C.c_int)]
 
 
 class TrlError(RuntimeError):
@@ -39,6 +39,7 @@ _SIGNATURES = {
     "trl_ingest_nv12": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
     "trl_debug_stage_boxes": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "trl_debug_level_counts": (C.c_int, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
+    "trl_debug_poison": (C.c_int, [_vp, _i]),
     "trl_debug_pnet_level": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),
     "trl_debug_rnet": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "trl_debug_onet": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
@@ -66,7 +67,7 @@ def load(path: str | None = None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.trl_abi_version() != 2:
+    if lib.trl_abi_version() != 3:
         raise ImportError("libtruely_hip ABI mismatch")
     _lib = lib
     return lib

@@ -30,13 +30,15 @@ int trl_default_config(trl_config* cfg) {
     cfg->max_faces = 64;
     cfg->pnet_mode = 0;
     cfg->embed_mode = 0;
+    cfg->embed_precision = 0;
     return TRL_OK;
 }
 
 int trl_create(const trl_config* cfg, trl_ctx** out) {
     if (!cfg || !out) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
     if (cfg->cap_level < 64 || cfg->cap_level > 3072 || cfg->cap_frame < 64 || cfg->cap_frame > 3072 || (cfg->cap_level & 3) ||
-        (cfg->cap_frame & 3) || cfg->min_face_size < 12 || cfg->max_faces < 1 || !(cfg->factor > 0.1 && cfg->factor < 0.99) || cfg->embed_mode < 0 || cfg->embed_mode > 2) {
+        (cfg->cap_frame & 3) || cfg->min_face_size < 12 || cfg->max_faces < 1 || !(cfg->factor > 0.1 && cfg->factor < 0.99) || cfg->embed_mode < 0 || cfg->embed_mode > 2 ||
+        cfg->embed_precision < 0 || cfg->embed_precision > 1) {
         trl_set_error("bad trl_config (capacities must be multiples of 4 in [64,3072], min_face_size >= 12)");
         return TRL_ERR_INVALID;
     }
@@ -55,6 +57,7 @@ int trl_destroy(trl_ctx* c) {
     if (!c) return TRL_OK;
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
+    for (auto& kv : c->W) if (kv.second.pt) (void)hipFree(kv.second.pt);
     if (c->wdev) (void)hipFree(c->wdev);
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->scratch.base) (void)hipFree(c->scratch.base);
@@ -235,6 +238,7 @@ extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
     TRL_HIP(hipMalloc((void**)&c->wdev, total));
     TRL_HIP(hipMemcpy(c->wdev, host.data(), total, hipMemcpyHostToDevice));
     c->wbytes = total;
+    for (auto& kv : c->W) if (kv.second.pt) (void)hipFree(kv.second.pt);
     c->W.clear(); c->V.clear();
     for (auto& p : items) {
         if (p.mat) { DevW w; w.p = (float*)(c->wdev + p.off); w.K = p.K; w.Cout = p.Cout; w.Kpad = p.Kpad; w.ld = p.ld; c->W[p.name] = w; }
@@ -243,6 +247,14 @@ extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
 
     TRL_CHECK(trl_pnet_prepare(c));
     c->rnet_front_mode = c->onet_front_mode = -1;
+    if (c->cfg.embed_precision == 1) {   // bf16 copies of the embedder's conv weights (all but the 3-channel stem and the final linear)
+        for (auto& kv : c->W) {
+            const std::string& nm = kv.first;
+            if (nm.rfind("facenet.", 0) != 0 || nm == "facenet.conv2d_1a.w" || nm == "facenet.last_linear.w") continue;
+            TRL_CHECK(trl_make_weight_bf16(&kv.second, nullptr));
+        }
+        TRL_HIP(hipDeviceSynchronize());
+    }
     c->have_weights = true;
     return TRL_OK;
 }
@@ -351,6 +363,31 @@ int trl_debug_stage_boxes(trl_ctx* c, int stage, int frame, float* h_boxes, int 
     *n_out = k;
     const int m = k < max_rows ? k : max_rows;
     if (m > 0) TRL_HIP(hipMemcpy(h_boxes, src + (size_t)frame * c->cfg.cap_frame * 5, (size_t)m * 20, hipMemcpyDeviceToHost));
+    return TRL_OK;
+}
+
+__global__ void k_poison_lds(unsigned word, int nwords) {
+    extern __shared__ unsigned lds_words[];
+    for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds_words[i] = word;
+    __syncthreads();
+    if (lds_words[(threadIdx.x * 97) % nwords] != word) __builtin_trap();   // keeps the stores alive
+}
+
+// Fills every byte of the activation workspaces with `byte` (0xFF = NaN patterns, 0x7F = huge finite floats): a
+// result that depends on workspace contents left by an earlier call or process shows up as a parity failure.
+int trl_debug_poison(trl_ctx* c, int byte) {
+    if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    TRL_HIP(hipDeviceSynchronize());
+    if (c->scratch.base) TRL_HIP(hipMemset(c->scratch.base, byte, c->scratch.cap));
+    if (c->arena.base) TRL_HIP(hipMemset(c->arena.base, byte, c->arena.cap));
+    // ... and the LDS of every CU (it keeps the previous kernel's contents): 1024 workgroups of 160 KB, one per CU at a time
+    const int lds_bytes = 160 * 1024;
+    TRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    const unsigned w = (unsigned)(byte & 0xFF) * 0x01010101u;
+    k_poison_lds<<<1024, 256, lds_bytes, 0>>>(w, lds_bytes / 4);
+    TRL_LAUNCH_CHECK();   // cascade lists: every call re-initialises what it reads
+    TRL_HIP(hipDeviceSynchronize());
     return TRL_OK;
 }
 

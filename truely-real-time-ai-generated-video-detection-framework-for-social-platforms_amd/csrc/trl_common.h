@@ -30,6 +30,8 @@ void trl_set_error(const char* fmt, ...);
 struct DevW {          // a weight matrix on the device, [Kpad][ld] row-major, zero padded
     float* p = nullptr;
     int K = 0, Cout = 0, Kpad = 0, ld = 0;
+    uint16_t* pt = nullptr;   // optional bf16 copy, TRANSPOSED [Cout rounded to 64][ldt] (k contiguous: the MFMA B operand)
+    int ldt = 0;              // K rounded up to 32
 };
 struct DevV {          // a per-channel vector, padded to a multiple of 128 floats
     float* p = nullptr;
@@ -42,6 +44,7 @@ struct Act {
     int n = 0, h = 0, w = 0, c = 0;   // c = channels of this view
     int ld = 0;                        // floats between consecutive pixels (>= c)
     int coff = 0;                      // channel offset of the view inside the pixel
+    bool bf = false;                   // elements are bf16 (2 bytes), p is then a uint16_t* in disguise (embed_precision = 1)
     size_t pixels() const { return (size_t)n * h * w; }
 };
 
@@ -57,6 +60,8 @@ struct ConvArgs {
     float* y; int ldy, yoff;
     int KH, KW, sh, sw, ph, pw, Cout, OH, OW, act;
     int M;                        // N*OH*OW
+    int lowp = 0;                 // 1: x, y, res are bf16 and the weights come from wt (conv_bf16, FaceNet only)
+    const uint16_t* wt = nullptr; int ldwt = 0;
 };
 
 // bump allocator over one device allocation
@@ -77,6 +82,13 @@ int trl_launch_conv(const ConvArgs& a, hipStream_t s);
 int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st,
                        int ceil_mode, float* y, int ldy, int yoff, int OH, int OW, hipStream_t s);
 int trl_launch_gap(const float* x, int N, int HW, int C, float* y, hipStream_t s);
+// reduced-precision embedder (trl_bf16.hip)
+int trl_launch_conv_bf16(const ConvArgs& a, hipStream_t s);
+int trl_launch_to_bf16(const float* x, size_t n, uint16_t* y, hipStream_t s);
+int trl_make_weight_bf16(DevW* w, hipStream_t s);
+int trl_launch_maxpool_bf16(const uint16_t* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st, uint16_t* y, int ldy,
+                            int yoff, int OH, int OW, hipStream_t s);
+int trl_launch_gap_bf16(const uint16_t* x, int N, int HW, int C, float* y, hipStream_t s);
 int trl_launch_l2norm512(const float* x, const uint8_t* valid, int n, float* y, hipStream_t s);
 int trl_launch_drift(const float* emb, const uint8_t* valid, int n, long long frame_count, int fps,
                      float* sims, uint8_t* flags, int32_t* result, hipStream_t s);

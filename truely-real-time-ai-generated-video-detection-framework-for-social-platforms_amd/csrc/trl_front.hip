@@ -44,7 +44,10 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
     constexpr int CLD = 36;                          // channel stride of the conv1 strip: float4 pooling reads, and the
                                                      // epilogue's rows 4*kq+q land 16 banks apart (conflict free)
     constexpr int MROWS = (SR * CW + 15) & ~15;      // strip rows padded to whole M-tiles: unguarded epilogue stores
-    __shared__ __attribute__((aligned(16))) float in_s[IN_N + 128];
+    // + zero tail: the zero-weight k = 27 pad of the last conv row reads in_s[IN_N + 3 x] for x < CW.  It must hold ZEROS, not
+    // just any finite value: stale LDS can contain NaN bit patterns and NaN * 0 would poison that conv output.
+    constexpr int IN_PAD = (3 * S + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) float in_s[IN_N + IN_PAD];
     __shared__ __attribute__((aligned(16))) float c1_s[MROWS * CLD];
     // per-wave column-sum strip (aliases c1_s, which is dead during the crop)
     constexpr int COLCAP = ((MROWS * CLD - 16) / 4 < 2048 ? (MROWS * CLD - 16) / 4 : 2048) & ~3;
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                 }
             }
         }
-        for (int p = IN_N + tid; p < IN_N + 128; p += 256) in_s[p] = 0.f;   // read by the zero-weight k = 27 pad
+        for (int p = IN_N + tid; p < IN_N + IN_PAD; p += 256) in_s[p] = 0.f;   // read by the zero-weight k = 27 pad
     }
     // ---- conv1 weights: B operands of both 16-channel N-tiles, in registers ----------------------------------
     float B0[7], B1[7];

@@ -13,10 +13,10 @@ struct Runner {
     hipStream_t s;
     int err = TRL_OK;
 
-    Act alloc(int n, int h, int w, int ch) {
+    Act alloc(int n, int h, int w, int ch, bool bf = false) {
         Act a;
-        a.n = n; a.h = h; a.w = w; a.c = ch; a.ld = ch; a.coff = 0;
-        a.p = (float*)c->scratch.alloc((size_t)n * h * w * ch * sizeof(float) + 64);
+        a.n = n; a.h = h; a.w = w; a.c = ch; a.ld = ch; a.coff = 0; a.bf = bf;
+        a.p = (float*)c->scratch.alloc((size_t)n * h * w * ch * (bf ? sizeof(uint16_t) : sizeof(float)) + 64);
         if (!a.p && err == TRL_OK) {
             trl_set_error("activation scratch exhausted (%zu of %zu bytes used)", c->scratch.off, c->scratch.cap);
             err = TRL_ERR_STATE;
@@ -34,7 +34,7 @@ struct Runner {
     Act conv(const Act& x, const DevW* w, const DevV* bias, const DevV* scale, const DevV* shift, const DevV* slope,
              int kh, int kw, int sh, int sw, int ph, int pw, int act, const Act* into, const Act* res, float res_scale) {
         const int OH = (x.h + 2 * ph - kh) / sh + 1, OW = (x.w + 2 * pw - kw) / sw + 1;
-        Act y = into ? *into : alloc(x.n, OH, OW, w ? w->Cout : 0);
+        Act y = into ? *into : alloc(x.n, OH, OW, w ? w->Cout : 0, x.bf);
         if (err != TRL_OK) return y;
         if (!w || w->K != kh * kw * x.c || (into && (into->h != OH || into->w != OW || into->c != w->Cout))) {
             trl_set_error("conv shape mismatch (K=%d expected %d)", w ? w->K : -1, kh * kw * x.c);
@@ -52,6 +52,18 @@ struct Runner {
         a.KH = kh; a.KW = kw; a.sh = sh; a.sw = sw; a.ph = ph; a.pw = pw;
         a.Cout = w->Cout; a.OH = OH; a.OW = OW; a.act = act;
         a.M = x.n * OH * OW;
+        if (x.bf) {   // reduced-precision embedder: bf16 in / out / residual, transposed bf16 weights
+            if (!w->pt || y.bf != true || (res && !res->bf) || act == TRL_ACT_PRELU) {
+                trl_set_error("bf16 conv without bf16 weights / destination");
+                err = TRL_ERR_STATE;
+                return y;
+            }
+            a.lowp = 1; a.wt = w->pt; a.ldwt = w->ldt;
+            if (res) a.res = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(res->p) + res->coff);
+            int st = trl_launch_conv_bf16(a, s);
+            if (st != TRL_OK) err = st;
+            return y;
+        }
         int st = trl_launch_conv(a, s);
         if (st != TRL_OK) err = st;
         return y;
@@ -73,8 +85,14 @@ struct Runner {
     }
     Act pool(const Act& x, int k, int st, int ceil_mode, const Act* into = nullptr) {
         const int OH = trl_pool_out(x.h, k, st, ceil_mode), OW = trl_pool_out(x.w, k, st, ceil_mode);
-        Act y = into ? *into : alloc(x.n, OH, OW, x.c);
+        Act y = into ? *into : alloc(x.n, OH, OW, x.c, x.bf);
         if (err != TRL_OK) return y;
+        if (x.bf) {
+            int e = trl_launch_maxpool_bf16(reinterpret_cast<const uint16_t*>(x.p), x.n, x.h, x.w, x.c, x.ld, x.coff, k, st,
+                                            reinterpret_cast<uint16_t*>(y.p), y.ld, y.coff, OH, OW, s);
+            if (e != TRL_OK) err = e;
+            return y;
+        }
         int e = trl_launch_maxpool(x.p, x.n, x.h, x.w, x.c, x.ld, x.coff, k, st, ceil_mode, y.p, y.ld, y.coff, OH, OW, s);
         if (e != TRL_OK) err = e;
         return y;
@@ -84,7 +102,7 @@ struct Runner {
 // The 1x1 branches that read the block input run as one fused conv (weights concatenated at load time);
 // the concat buffer doubles as their scratch: a slice is only overwritten after its last reader has run.
 Act block35(Runner& R, const Act& x, const std::string& p) {
-    Act cat = R.alloc(x.n, x.h, x.w, 96);
+    Act cat = R.alloc(x.n, x.h, x.w, 96, x.bf);
     Act s1 = Runner::slice(cat, 32, 32), s2 = Runner::slice(cat, 64, 32);
     R.bconv(x, p + ".fused", 1, 1, 1, 1, 0, 0, &cat);                 // [branch0 | branch2.0 | branch1.0]
     Act b2 = R.bconv(s1, p + ".branch2.1", 3, 3, 1, 1, 1, 1);         // reads branch2.0 (cols 32:64)
@@ -93,7 +111,7 @@ Act block35(Runner& R, const Act& x, const std::string& p) {
     return R.resid(cat, x, p + ".conv2d", 0.17f, true);
 }
 Act block17(Runner& R, const Act& x, const std::string& p) {
-    Act cat = R.alloc(x.n, x.h, x.w, 256);
+    Act cat = R.alloc(x.n, x.h, x.w, 256, x.bf);
     Act s1 = Runner::slice(cat, 128, 128);
     R.bconv(x, p + ".fused", 1, 1, 1, 1, 0, 0, &cat);                 // [branch0 | branch1.0]
     Act a2 = R.bconv(s1, p + ".branch1.1", 1, 7, 1, 1, 0, 3);
@@ -101,7 +119,7 @@ Act block17(Runner& R, const Act& x, const std::string& p) {
     return R.resid(cat, x, p + ".conv2d", 0.10f, true);
 }
 Act block8(Runner& R, const Act& x, const std::string& p, float scale, bool relu) {
-    Act cat = R.alloc(x.n, x.h, x.w, 384);
+    Act cat = R.alloc(x.n, x.h, x.w, 384, x.bf);
     Act s1 = Runner::slice(cat, 192, 192);
     R.bconv(x, p + ".fused", 1, 1, 1, 1, 0, 0, &cat);                 // [branch0 | branch1.0]
     Act a2 = R.bconv(s1, p + ".branch1.1", 1, 3, 1, 1, 0, 1);
@@ -118,6 +136,12 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
     Act x0; x0.p = const_cast<float*>(d_faces); x0.n = n; x0.h = h; x0.w = w; x0.c = 3; x0.ld = 3; x0.coff = 0;
     const std::string f = "facenet.";
     Act x = R.bconv(x0, f + "conv2d_1a", 3, 3, 2, 2, 0, 0);
+    if (c->cfg.embed_precision == 1) {   // everything after the 3-channel stem conv runs on bf16 activations (trl_bf16.hip)
+        Act xb = R.alloc(x.n, x.h, x.w, x.c, true);
+        if (R.err != TRL_OK) return R.err;
+        TRL_CHECK(trl_launch_to_bf16(x.p, x.pixels() * x.c, reinterpret_cast<uint16_t*>(xb.p), s));
+        x = xb;
+    }
     x = R.bconv(x, f + "conv2d_2a", 3, 3, 1, 1, 0, 0);
     x = R.bconv(x, f + "conv2d_2b", 3, 3, 1, 1, 1, 1);
     x = R.pool(x, 3, 2, 0);
@@ -129,7 +153,7 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
     for (int i = 0; i < 5; i++) x = block35(R, x, f + "repeat_1." + std::to_string(i));
     {   // Mixed_6a
         const int OH = (x.h - 3) / 2 + 1, OW = (x.w - 3) / 2 + 1;
-        Act cat = R.alloc(n, OH, OW, 896);
+        Act cat = R.alloc(n, OH, OW, 896, x.bf);
         Act s0 = Runner::slice(cat, 0, 384), s1 = Runner::slice(cat, 384, 256), s2 = Runner::slice(cat, 640, 256);
         R.bconv(x, f + "mixed_6a.branch0", 3, 3, 2, 2, 0, 0, &s0);
         Act a = R.bconv(x, f + "mixed_6a.branch1.0", 1, 1, 1, 1, 0, 0);
@@ -143,7 +167,7 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
     for (int i = 0; i < 10; i++) x = block17(R, x, f + "repeat_2." + std::to_string(i));
     {   // Mixed_7a
         const int OH = (x.h - 3) / 2 + 1, OW = (x.w - 3) / 2 + 1;
-        Act cat = R.alloc(n, OH, OW, 1792);
+        Act cat = R.alloc(n, OH, OW, 1792, x.bf);
         Act s0 = Runner::slice(cat, 0, 384), s1 = Runner::slice(cat, 384, 256), s2 = Runner::slice(cat, 640, 256),
             s3 = Runner::slice(cat, 896, 896);
         Act t = R.bconv(x, f + "mixed_7a.fused", 1, 1, 1, 1, 0, 0);   // [branch0.0 | branch1.0 | branch2.0]
@@ -161,7 +185,8 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
     // avgpool_1a -> last_linear (no bias) -> last_bn (folded) -> F.normalize
     Act g = R.alloc(n, 1, 1, x.c);
     if (R.err != TRL_OK) return R.err;
-    TRL_CHECK(trl_launch_gap(x.p, n, x.h * x.w, x.c, g.p, s));
+    if (x.bf) TRL_CHECK(trl_launch_gap_bf16(reinterpret_cast<const uint16_t*>(x.p), n, x.h * x.w, x.c, g.p, s));
+    else TRL_CHECK(trl_launch_gap(x.p, n, x.h * x.w, x.c, g.p, s));
     Act e = R.conv(g, trl_w(c, f + "last_linear.w"), nullptr, trl_v(c, f + "last_bn.scale"), trl_v(c, f + "last_bn.shift"),
                    nullptr, 1, 1, 1, 1, 0, 0, TRL_ACT_NONE, nullptr, nullptr, 0.f);
     if (R.err != TRL_OK) return R.err;

@@ -24,7 +24,8 @@ def _ptr(t: Optional[torch.Tensor]):
 class Engine:
     def __init__(self, blob: bytes | None = None, device: int | None = None, pnet_mode: int | None = None,
                  cap_level: int | None = None, cap_frame: int | None = None, min_face_size: int = 20,
-                 thresholds=(0.6, 0.7, 0.7), factor: float = 0.709, max_faces: int = 64, embed_mode: int = 0):
+                 thresholds=(0.6, 0.7, 0.7), factor: float = 0.709, max_faces: int = 64, embed_mode: int = 0,
+                 embed_precision: str | int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("truely_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _lib.load()
@@ -36,6 +37,7 @@ class Engine:
         cfg.factor = float(factor)
         cfg.max_faces = int(max_faces)
         cfg.embed_mode = int(embed_mode)
+        cfg.embed_precision = {"f32": 0, "fp32": 0, "bf16": 1}.get(embed_precision, embed_precision) if isinstance(embed_precision, str) else int(embed_precision)
         if pnet_mode is not None:
             cfg.pnet_mode = int(pnet_mode)
         if cap_level:
@@ -138,6 +140,10 @@ class Engine:
         k = C.c_int()
         _lib.check(self.lib.trl_debug_stage_boxes(self._h, stage, frame, buf.ctypes.data_as(C.c_void_p), max_rows, C.byref(k)))
         return buf[:min(k.value, max_rows)].copy()
+
+    def poison_workspaces(self, byte: int = 0xFF):
+        """Test hook: fill the activation workspaces with a byte pattern (0xFF = NaNs)."""
+        _lib.check(self.lib.trl_debug_poison(self._h, int(byte)))
 
     def level_counts(self, frame: int):
         a = np.zeros(32, np.int32); b = np.zeros(32, np.int32)
