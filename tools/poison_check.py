@@ -6,7 +6,10 @@ from truely_amd.engine import Engine
 blob = truely_amd.weights.synthetic_blob(0)
 sets = [truely_amd.synthetic.synthetic_frames(6, 180, 320, seed=3), truely_amd.synthetic.synthetic_frames(5, 97, 131, seed=21),
         truely_amd.synthetic.synthetic_frames(8, 360, 640, seed=11), truely_amd.synthetic.synthetic_frames(16, 720, 1280, seed=0)]
-eng = Engine(blob)
+import sys
+mode = sys.argv[1] if len(sys.argv) > 1 else "default"
+eng = {"default": lambda: Engine(blob), "native": lambda: Engine(blob, embed_mode=2), "bf16": lambda: Engine(blob, embed_precision="bf16"),
+       "generic_pnet": lambda: Engine(blob, pnet_mode=1)}[mode]()
 ref = []
 for fr in sets:
     out = eng.detect_embed(fr)
@@ -22,4 +25,4 @@ for byte in (0xFF, 0x7F, 0x00, 0xFF):
                 bad += 1
                 d = np.abs(ref[si][k].astype(np.float64) - b.astype(np.float64))
                 print(f"poison 0x{byte:02X} set {si} key {k}: max diff {np.nanmax(d):.3e} nan={int(np.isnan(b.astype(np.float64)).sum())}")
-print("mismatches:", bad)
+print(mode, "mismatches:", bad)
