@@ -182,3 +182,24 @@ def test_results_do_not_depend_on_stale_memory(engine, oracle, byte):
         ref = oracle.detect_embed(fr)
         for k in ("box", "prob", "rect", "valid", "emb"):
             assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+
+
+@pytest.mark.parametrize("offset", [4, 8, 12])
+def test_frame_buffer_at_dword_alignment_only(engine, oracle, offset):
+    """The C ABI asks for a 4-byte aligned frame pointer, not 16: a batch living at +4/+8/+12 bytes inside a larger
+    device allocation, with 0xFF guard bytes on both sides, must give the same bits (dword-aligned 16-byte loads,
+    clamped reads at the end of the buffer)."""
+    import torch
+    fr = truely_amd.synthetic.synthetic_frames(3, 97, 131, seed=21)        # odd row pitch: frames start at every byte phase
+    nbytes = fr.size
+    big = torch.full((nbytes + 64,), 0xFF, dtype=torch.uint8, device="cuda")
+    view = big[offset:offset + nbytes]
+    view.copy_(torch.from_numpy(fr.reshape(-1)))
+    dev = view.view(fr.shape)
+    assert dev.data_ptr() % 16 == offset % 16 and dev.is_contiguous()
+    engine.poison_workspaces(0xFF)
+    out = engine.detect_embed(dev)
+    ref = oracle.detect_embed(fr)
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+    assert bool((big[:offset] == 0xFF).all()) and bool((big[offset + nbytes:] == 0xFF).all())
