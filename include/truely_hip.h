@@ -120,6 +120,9 @@ int  trl_ingest_nv12(trl_ctx* ctx, const uint8_t* d_nv12, int n_in, int H, int W
 int  trl_debug_stage_boxes(trl_ctx* ctx, int stage, int frame, float* h_boxes, int max_rows, int* n_out);
 /* Per-level PNet candidate / kept counts of one frame (host output, up to 32 levels each). */
 int  trl_debug_level_counts(trl_ctx* ctx, int frame, int32_t* h_cand, int32_t* h_keep, int* n_levels);
+/* test hook: level `level` of one frame's image pyramid as the fused PNet kernel reads it; d_out holds h*w*3 floats
+ * (capacity: at least (int(H*m+1))*(int(W*m+1))*3 with m = 12/min_face_size) */
+int  trl_debug_pyramid_level(trl_ctx* ctx, const uint8_t* d_frame, int H, int W, int level, float* d_out, int* h, int* w, void* stream);
 /* test hook: fill the activation workspaces with a byte pattern (0xFF -> NaNs) before the next call */
 int  trl_debug_poison(trl_ctx* ctx, int byte);
 /* PNet on one pyramid level of frame 0: face-prob map and regression map (device outputs). */

@@ -203,3 +203,21 @@ def test_frame_buffer_at_dword_alignment_only(engine, oracle, offset):
     for k in ("box", "prob", "rect", "valid", "emb"):
         assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
     assert bool((big[:offset] == 0xFF).all()) and bool((big[offset + nbytes:] == 0xFF).all())
+
+
+@pytest.mark.parametrize("H,W", [(180, 320), (97, 131), (720, 1280), (1080, 1920), (2160, 3840)])
+def test_pyramid_levels_bit_exact(engine, oracle, H, W):
+    """Every level of the production pyramid (what the fused PNet kernel reads) against imresample + normalise of the
+    oracle, pixel for pixel.  4K exercises the multiply-high row decode beyond its exact range (fix-up step), table
+    driven bin edges and bins too large for the reciprocal division."""
+    fr = truely_amd.synthetic.synthetic_frames(1, H, W, seed=5)[0]
+    scales = oracle.scales(H, W)
+    levels = range(len(scales)) if H <= 720 else (0, 1, 2, 3, len(scales) // 2, len(scales) - 1)
+    for level in levels:
+        _sc, h, w = scales[level]
+        ref = oracle.area_resample_norm(fr, 0, H, 0, W, h, w)
+        engine.poison_workspaces(0xFF)
+        got = engine.pyramid_level(fr, level).cpu().numpy()
+        assert got.shape == ref.shape, (level, got.shape, ref.shape)
+        bad = np.argwhere(got != ref)
+        assert bad.size == 0, f"level {level} ({h}x{w}): {len(bad)} pixels differ, first at {bad[:3].tolist()}"

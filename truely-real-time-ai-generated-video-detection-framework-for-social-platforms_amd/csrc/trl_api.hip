@@ -401,6 +401,16 @@ int trl_debug_level_counts(trl_ctx* c, int frame, int32_t* h_cand, int32_t* h_ke
     return TRL_OK;
 }
 
+int trl_debug_pyramid_level(trl_ctx* c, const uint8_t* d_frame, int H, int W, int level, float* d_out, int* h, int* w, void* stream) {
+    TRL_CHECK(check_call(c, d_frame, 1, H, W));
+    hipStream_t s = (hipStream_t)stream;
+    c->scratch.reset();
+    TRL_CHECK(trl_ensure(c, c->scratch, trl_pnet_fused_bytes(c, 1, H, W) + (1u << 20)));
+    TRL_CHECK(trl_pyramid_export(c, d_frame, H, W, level, d_out, h, w, s));
+    TRL_HIP(hipStreamSynchronize(s));
+    return TRL_OK;
+}
+
 int trl_debug_pnet_level(trl_ctx* c, const uint8_t* d_frame, int H, int W, int level, float* d_prob, float* d_reg, int* oh, int* ow,
                          void* stream) {
     TRL_CHECK(check_call(c, d_frame, 1, H, W));

@@ -85,3 +85,4 @@ int trl_compute_levels(trl_ctx* c, int H, int W);
 int trl_pnet_prepare(trl_ctx* c);
 size_t trl_pnet_fused_bytes(trl_ctx* c, int n, int H, int W);
 int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipEvent_t* ev, hipStream_t s);
+int trl_pyramid_export(trl_ctx* c, const uint8_t* d_frame, int H, int W, int level, float* d_out, int* h, int* w, hipStream_t s);

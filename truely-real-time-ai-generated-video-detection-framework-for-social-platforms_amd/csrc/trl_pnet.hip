@@ -162,7 +162,9 @@ __device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ frames, co
         unsigned s0 = 0, s1 = 0, s2 = 0;
         int kh = 1, kw = 1;
         if (valid) {
-            const int oy = (int)__umulhi((unsigned)pixel, g.wmagic), ox = pixel - oy * w;
+            int oy = (int)__umulhi((unsigned)pixel, g.wmagic);       // floor(pixel / w) or one above it (large levels): fix up
+            oy -= (oy * w > pixel) ? 1 : 0;
+            const int ox = pixel - oy * w;
             const uint32_t ty = tab[g.ytab0 + oy], tx = tab[g.xtab0 + ox];
             const int ys = ty & 0xFFFF, ye = ty >> 16, xs = tx & 0xFFFF, xe = tx >> 16;
             kh = ye - ys; kw = xe - xs;
@@ -256,7 +258,9 @@ __device__ __forceinline__ void pyr_level0(const uint8_t* __restrict__ frames, c
         const bool valid = pixel < g.h * g.w;
         float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) {
-            const int oy = (int)__umulhi((unsigned)pixel, g.wmagic), ox = pixel - oy * g.w;
+            int oy = (int)__umulhi((unsigned)pixel, g.wmagic);       // floor(pixel / w) or one above it (large levels): fix up
+            oy -= (oy * g.w > pixel) ? 1 : 0;
+            const int ox = pixel - oy * g.w;
             int ys, kh, xs, kw;
             if (g.arith) {   // adaptive_avg_pool2d edges [floor(i*in/out), ceil((i+1)*in/out)) without touching memory
                 ys = (int)__umulhi((unsigned)(oy * a.H), g.hmagic);
@@ -791,10 +795,10 @@ size_t trl_pnet_fused_bytes(trl_ctx* c, int n, int H, int W) {
 
 // All pyramid levels of all n frames: pyramid kernel + one persistent fused launch.
 // ev[0..1] bracket the pyramid kernel, ev[2..3] the fused kernel (HIP events on the same stream).
-int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipEvent_t* ev, hipStream_t s) {
+// The pyramid of all n frames (production path of both the fused PNet and the debug export below).
+static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, PnetArgs& a, hipEvent_t* ev, hipStream_t s) {
     if (((uintptr_t)d_frames & 3) != 0) { trl_set_error("frame buffer must be 4-byte aligned"); return TRL_ERR_INVALID; }
     if (H > 16383 || W > 16383) { trl_set_error("frame larger than 16383 px"); return TRL_ERR_INVALID; }
-    PnetArgs a;
     std::vector<uint32_t> tab;
     const bool new_shape = (c->pyr_tab == nullptr || c->pyr_tab_H != H || c->pyr_tab_W != W);
     TRL_CHECK(fill_args(c, n, H, W, a, new_shape ? &tab : nullptr));
@@ -829,7 +833,32 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
             TRL_LAUNCH_CHECK();
         }
     }
-    if (ev) { TRL_HIP(hipEventRecord(ev[1], s)); TRL_HIP(hipEventRecord(ev[2], s)); }
+    if (ev) TRL_HIP(hipEventRecord(ev[1], s));
+    return TRL_OK;
+}
+
+// debug / test hook: level `level` of ONE frame's pyramid exactly as the fused PNet kernel reads it -> d_out [h][w][3]
+__global__ void k_export_level(const float4* __restrict__ pyr, int npix, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float4 v = pyr[i];
+    out[3 * i + 0] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+}
+int trl_pyramid_export(trl_ctx* c, const uint8_t* d_frame, int H, int W, int level, float* d_out, int* h, int* w, hipStream_t s) {
+    PnetArgs a;
+    TRL_CHECK(build_pyramid(c, d_frame, 1, H, W, a, nullptr, s));
+    if (level < 0 || level >= a.L) { trl_set_error("level %d out of range (%d levels)", level, a.L); return TRL_ERR_INVALID; }
+    const PLevel& g = a.lv[level];
+    k_export_level<<<(g.h * g.w + 255) / 256, 256, 0, s>>>(a.pyr + g.pix0, g.h * g.w, d_out);
+    TRL_LAUNCH_CHECK();
+    *h = g.h; *w = g.w;
+    return TRL_OK;
+}
+
+int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipEvent_t* ev, hipStream_t s) {
+    PnetArgs a;
+    TRL_CHECK(build_pyramid(c, d_frames, n, H, W, a, ev, s));
+    if (ev) TRL_HIP(hipEventRecord(ev[2], s));
     const int total_tiles = a.tiles_per_frame * n;
     int grid = 256 * 2;                       // 2 resident workgroups per CU (<= 256 VGPRs)
     if (grid > ((total_tiles + 7) / 8) * 8) grid = ((total_tiles + 7) / 8) * 8;

@@ -141,6 +141,16 @@ class Engine:
         _lib.check(self.lib.trl_debug_stage_boxes(self._h, stage, frame, buf.ctypes.data_as(C.c_void_p), max_rows, C.byref(k)))
         return buf[:min(k.value, max_rows)].copy()
 
+    def pyramid_level(self, frame, level: int) -> torch.Tensor:
+        """Test hook: pyramid level of one frame as the fused PNet kernel reads it, (h, w, 3) float32."""
+        fr = self._frames(frame[None] if getattr(frame, "ndim", 4) == 3 else frame)
+        _, H, W, _ = fr.shape
+        m = 12.0 / self.cfg.min_face_size
+        out = torch.empty((int(H * m + 1) * int(W * m + 1) * 3,), dtype=torch.float32, device=self.device)
+        h, w = C.c_int(), C.c_int()
+        _lib.check(self.lib.trl_debug_pyramid_level(self._h, _ptr(fr), H, W, int(level), _ptr(out), C.byref(h), C.byref(w), self._stream()))
+        return out[:h.value * w.value * 3].view(h.value, w.value, 3)
+
     def poison_workspaces(self, byte: int = 0xFF):
         """Test hook: fill the activation workspaces with a byte pattern (0xFF = NaNs)."""
         _lib.check(self.lib.trl_debug_poison(self._h, int(byte)))
