@@ -57,11 +57,12 @@ def test_drift_is_a_function_of_time_order_only(engine, clip720):
 @pytest.mark.parametrize("H,W,faces,seed", [(1080, 1920, -1, 31), (2160, 3840, 1, 32)])
 def test_large_frames_against_oracle(engine, blob, oracle, H, W, faces, seed):
     """configs[2] (1080p, 3-5 faces) and configs[4] (4K, min_face_size=20 -> 14 pyramid levels), fp32 path."""
-    engine.poison_workspaces(0xFF)   # NaN-filled workspaces and LDS: see test_results_do_not_depend_on_stale_memory
     if H > 1080:   # a 4K frame has ~3x the candidates of the default list capacity: use the largest lists
         from truely_amd.engine import Engine
         engine = Engine(blob, cap_level=3072, cap_frame=3072)
     fr = truely_amd.synthetic.synthetic_frames(1, H, W, seed=seed, faces=faces)
+    engine.detect_embed(fr)          # sizes the workspaces ...
+    engine.poison_workspaces(0xFF)   # ... which are then NaN-filled, like the LDS: see test_results_do_not_depend_on_stale_memory
     out = engine.detect_embed(fr)
     _b, _p, tr = oracle.detect(fr[0], trace=True)
     cand, keep = engine.level_counts(0)
