@@ -106,7 +106,7 @@ int trl_ensure(trl_ctx* c, Arena& a, size_t bytes) {
     TRL_HIP(hipMalloc((void**)&a.base, ncap));
     a.cap = ncap;
     a.off = 0;
-    (void)c;
+    if (c->dbg_poison >= 0) TRL_HIP(hipMemset(a.base, c->dbg_poison, ncap));   // test hook: workspaces that grow stay poisoned
     return TRL_OK;
 }
 
@@ -379,6 +379,7 @@ int trl_debug_poison(trl_ctx* c, int byte) {
     if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
     TRL_HIP(hipSetDevice(c->cfg.device));
     TRL_HIP(hipDeviceSynchronize());
+    c->dbg_poison = byte & 0xFF;                 // sticky: blocks allocated later are filled too
     if (c->scratch.base) TRL_HIP(hipMemset(c->scratch.base, byte, c->scratch.cap));
     if (c->arena.base) TRL_HIP(hipMemset(c->arena.base, byte, c->arena.cap));
     // ... and the LDS of every CU (it keeps the previous kernel's contents): 1024 workgroups of 160 KB, one per CU at a time
