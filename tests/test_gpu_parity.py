@@ -221,3 +221,25 @@ def test_pyramid_levels_bit_exact(engine, oracle, H, W):
         assert got.shape == ref.shape, (level, got.shape, ref.shape)
         bad = np.argwhere(got != ref)
         assert bad.size == 0, f"level {level} ({h}x{w}): {len(bad)} pixels differ, first at {bad[:3].tolist()}"
+
+
+@pytest.mark.parametrize("kind", ["noise", "edges", "saturated"])
+def test_cascade_stress_inputs(blob, oracle, kind):
+    """Inputs chosen to stress the cascade plumbing rather than to look like faces: uniform noise (hundreds of
+    candidates per level, boxes hanging over every border -> crop clamps, NMS ties), hard-edged blocks (identical
+    scores -> tie-breaks), saturated frames (0 / 255 -> integer sums at their extremes)."""
+    from truely_amd.engine import Engine
+    rng = np.random.default_rng(77)
+    if kind == "noise":
+        fr = rng.integers(0, 256, (3, 150, 210, 3), dtype=np.uint8)
+    elif kind == "edges":
+        fr = np.zeros((3, 144, 192, 3), np.uint8)
+        for i in range(3):
+            for by in range(0, 144, 24):
+                for bx in range(0, 192, 24):
+                    fr[i, by:by + 24, bx:bx + 24] = 255 if ((by // 24 + bx // 24 + i) % 2) else 30
+    else:
+        fr = np.stack([np.full((120, 160, 3), 255, np.uint8), np.zeros((120, 160, 3), np.uint8),
+                       np.concatenate([np.full((60, 160, 3), 255, np.uint8), np.zeros((60, 160, 3), np.uint8)])])
+    eng = Engine(blob, cap_level=3072, cap_frame=3072)
+    _check_cascade(eng, oracle, fr)
