@@ -1,6 +1,7 @@
 // trl_front.hip -- fused front end of R-Net / O-Net for gfx950 (detect_face stages 2 and 3):
 //   crop [y-1:ey, x-1:ex] of the u8 frame -> imresample to SxS -> (v-127.5)*0.0078125
-//   -> conv1 3x3 (3->28 / 3->32) + PReLU -> MaxPool(3, 2, ceil_mode)            (one workgroup per candidate)
+//   -> conv1 3x3 (3->28 / 3->32) + PReLU -> MaxPool(3, 2, ceil_mode)            (one workgroup per candidate;
+//      PReLU moves behind the pool when the slopes are monotone, see MODE)
 // The conv1 activation (54 KB / 271 KB per candidate) never leaves LDS: only the pooled map is written,
 // which removes ~7.6 GB of HBM traffic per 256-frame batch.  conv1 runs on v_mfma_f32_16x16x4_f32 with the
 // weights in registers, k ascending from the bias: bit-identical to the oracle's conv2d chain.

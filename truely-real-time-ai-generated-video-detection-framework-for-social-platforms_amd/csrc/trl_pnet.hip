@@ -1,11 +1,13 @@
 // trl_pnet.hip -- MTCNN stage 1 (PNet over the image pyramid) for gfx950, the dominant kernel of the
 // hot path (83 % of the conv FLOPs at 720p; server/model.py:47 -> detect_face stage 1).
 //
-// Two launches per batch of frames:
+// Per batch of frames: one k_pyramid launch per (level, Infinity-Cache-sized frame chunk), then ONE fused launch.
 //
 //  k_pyramid      u8 BGR frames -> every pyramid level, imresample (F.interpolate mode="area") +
-//                 (x-127.5)*0.0078125, stored as float4 {b,g,r,0} per pixel.  One thread per output
-//                 pixel, aligned dword loads + v_dot4 byte sums (integer-exact, order independent).
+//                 (x-127.5)*0.0078125, stored as float4 {b,g,r,0} per pixel (streamed past the caches).  One
+//                 lane (fine levels) or lane group (coarse levels) per output pixel, dword-aligned 16/12-byte
+//                 loads + v_dot4 byte sums (integer-exact, order independent), bin edges by exact multiply-high
+//                 division, bin mean by the exhaustively verified reciprocal division (pyr_div).
 //
 //  k_pnet_fused   ONE persistent launch over all (frame, level, 16x16-cell tile) work items.  Per tile,
 //                 entirely in LDS / registers:
@@ -16,8 +18,11 @@
 //                 All four layers run on the f32 matrix cores (v_mfma_f32_16x16x4_f32 for N<=16,
 //                 v_mfma_f32_32x32x2_f32 for conv3), k ascending, accumulator seeded with the bias: the
 //                 same fmaf chain as the oracle, so maps and candidates are bit-identical.
-//                 Every weight matrix lives in registers for the whole launch (B operands: 7+23+72+8
-//                 VGPRs per lane), activations never leave the CU: HBM traffic is the pyramid read only.
+//                 conv1 / conv2 / head weights live in registers for the whole launch (B operands: 7+23+8
+//                 VGPRs per lane), conv3's in LDS; activations never leave the CU: HBM traffic is the pyramid
+//                 read only.  f32 MFMA and VALU share the FP32 pipe, so the loops carry almost no VALU: the
+//                 tile decode is scalar (multiply-high by host magic numbers), LDS addresses are lane bases +
+//                 compile-time offsets, pooling precedes PReLU when the slopes allow, edge logic only on edge tiles.
 //                 blockIdx -> tile mapping keeps an XCD on a contiguous run of tiles (halo rows of
 //                 neighbouring tiles hit the same L2).
 #include "trl_ctx.h"
