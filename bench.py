@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pnet-mode", type=int, default=None)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo to rehearse the N>1 path on one GPU")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight per GPU: each gets its own context, HIP stream and host thread, so the low-occupancy tail "
+                         "of one batch (NMS, FaceNet's 1x1-spatial layers) overlaps the wide kernels of the next; 1 = strictly sequential")
     args = ap.parse_args()
 
     import numpy as np
@@ -97,34 +100,77 @@ def main():
     n = args.batch
     frames_np = truely_amd.synthetic.synthetic_frames(n, H, W, seed=rank, faces=1)
     frames = torch.from_numpy(frames_np).to(dev)
-    eng = Engine(truely_amd.weights.synthetic_blob(0), device=local, pnet_mode=args.pnet_mode)
+    import queue
+    import threading
+    blob = truely_amd.weights.synthetic_blob(0)
+    F = max(1, args.in_flight)
+    engs = [Engine(blob, device=local, pnet_mode=args.pnet_mode) for _ in range(F)]   # one context + workspace per batch in flight
+    streams = [torch.cuda.Stream(dev) for _ in range(F)]
+    eng = engs[0]
+    drift_eng = Engine(blob, device=local) if F > 1 else eng      # the main thread's context (drift kernels)
     frame_count = n * world * 4      # 30 fps clip sampled every 4th frame (model.py:40)
 
-    def step():
-        out = eng.detect_embed(frames)
+    def finish(out):
+        """Main thread, step order on every rank: the one collective of the path, then the drift state machine."""
         if world > 1:
             emb, valid = allgather_embeddings(out["emb"], out["valid"])
         else:
             emb, valid = out["emb"], out["valid"]
-        d = eng.drift_score(emb, valid, frame_count, FPS)
-        return out, d
+        return drift_eng.drift_score(emb, valid, frame_count, FPS)
+
+    def run_steps(k):
+        """k steps.  Worker j runs detect+embed of steps j, j+F, .. on its own stream; results are consumed in step order."""
+        acc = {"pnet_ms": 0.0, "pyramid_ms": 0.0}
+        last = (None, None)
+        if F == 1:
+            for _ in range(k):
+                out = eng.detect_embed(frames)
+                d = finish(out)
+                tm = eng.timings()
+                acc["pnet_ms"] += tm["pnet_ms"]; acc["pyramid_ms"] += tm["pyramid_ms"]
+                last = (out, d)
+            return last, acc
+        qs = [queue.Queue() for _ in range(F)]
+
+        def worker(j):
+            try:
+                torch.cuda.set_device(local)
+                with torch.cuda.stream(streams[j]):
+                    for _i in range(j, k, F):
+                        out = engs[j].detect_embed(frames)
+                        streams[j].synchronize()          # the consumer runs on another stream
+                        qs[j].put((out, engs[j].timings()))
+            except BaseException as e:                     # surfaced by the consumer
+                qs[j].put(e)
+
+        ths = [threading.Thread(target=worker, args=(j,), daemon=True) for j in range(F)]
+        for t in ths:
+            t.start()
+        for i in range(k):
+            item = qs[i % F].get()
+            if isinstance(item, BaseException):
+                raise item
+            out, tm = item
+            d = finish(out)
+            acc["pnet_ms"] += tm["pnet_ms"]; acc["pyramid_ms"] += tm["pyramid_ms"]
+            last = (out, d)
+        for t in ths:
+            t.join()
+        return last, acc
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out, d = step()
+    if args.warmup > 0:
+        run_steps(max(args.warmup, F))
     fence()
-    pnet_ms = pyr_ms = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, d = step()
-        tm = eng.timings()
-        pnet_ms += tm["pnet_ms"]; pyr_ms += tm["pyramid_ms"]
+    (out, d), acc = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    pnet_ms, pyr_ms = acc["pnet_ms"], acc["pyramid_ms"]
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -150,7 +196,8 @@ def main():
                        "frames_per_gpu": n, "height": H, "width": W, "weights": "seeded synthetic (no checkpoints offline)",
                        "valid_faces": int(out["valid"].sum().item()), "score": d["score"],
                        "pnet_path": "fused" if eng.cfg.pnet_mode == 0 else "generic layers",
-                       "parallelism": f"frame-sharded x{world}, 1 all-gather of embeddings" if world > 1 else "single GPU"},
+                       "parallelism": f"frame-sharded x{world}, 1 all-gather of embeddings" if world > 1 else "single GPU",
+                       "batches_in_flight": F},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "kernel": "k_pnet_fused (PNet over the pyramid: 83% of the conv FLOPs at 720p)",
