@@ -174,3 +174,36 @@ def test_bf16_embedder_mode(blob, oracle):
     dref = oracle.drift_score(exp["emb"], exp["valid"], len(fr) * 4, 30)
     sims, sref = d["sims"].cpu().numpy(), np.asarray(dref["sims"])
     assert np.abs(sims - sref).max() <= 5e-2
+
+
+def test_two_contexts_on_two_threads(blob):
+    """bench.py keeps two batches in flight: two contexts, two HIP streams, two host threads.  Results must be the
+    bits a single context produces (no shared mutable state in the library besides per-context workspaces)."""
+    import threading
+    from truely_amd.engine import Engine
+    sets = [truely_amd.synthetic.synthetic_frames(12, 360, 640, seed=s) for s in (41, 42)]
+    single = Engine(blob)
+    ref = [{k: v.cpu().numpy() for k, v in single.detect_embed(fr).items()} for fr in sets]
+    engs = [Engine(blob), Engine(blob)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got, errs = [None, None], []
+
+    def worker(j):
+        try:
+            with torch.cuda.stream(streams[j]):
+                for _ in range(6):
+                    out = engs[j].detect_embed(sets[j])
+                streams[j].synchronize()
+                got[j] = {k: v.cpu().numpy() for k, v in out.items()}
+        except BaseException as e:
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(j,)) for j in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for j in range(2):
+        for k in ("box", "prob", "rect", "valid", "emb"):
+            assert np.array_equal(got[j][k], ref[j][k]), (j, k)
