@@ -573,6 +573,141 @@ __global__ __launch_bounds__(256) void conv_tap(ConvArgs a) {
     }
 }
 
+// conv_tap48: whole-tap implicit GEMM for Cout = 48 (R-Net conv2, 31 k candidates x 81 pixels per step): a 128 x 48 tile on
+// v_mfma_f32_16x16x4_f32 -- three 16-column tiles instead of two 32-column ones, so no MFMA cycle is spent on the 16 padding
+// columns a 64-wide tile would carry (25 % of that layer).  Same LDS layout ([k][m], [k][n]) and loader as conv_tap; each of the
+// 4 waves owns 32 rows = 2 x 3 accumulator tiles; k = 4s + (lane >> 4) ascending, bias-seeded: the oracle's chain.
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+template <int BK, bool PAD>
+__global__ __launch_bounds__(256) void conv_tap48(ConvArgs a) {
+    constexpr int BM = 128, BN = 48;
+    constexpr int KG = BK / 4;
+    constexpr int ASLOTS = BM * KG, APT = (ASLOTS + 255) / 256;
+    constexpr int BSLOTS = BK * (BN / 4), BPT = (BSLOTS + 255) / 256;
+    constexpr int GSTEP = 256 / BM;
+    static_assert(BK % 4 == 0, "k-steps of 4");
+    __shared__ __attribute__((aligned(16))) float As[BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+
+    const int row = tid % BM, g0 = tid / BM;
+    const int m = m0 + row;
+    const int mm = m < a.M ? m : 0;
+    const int ohw = a.OH * a.OW;
+    const int nimg = mm / ohw;
+    const int rem = mm - nimg * ohw;
+    const int oy = rem / a.OW, ox = rem - oy * a.OW;
+    const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
+    const int aoff = ((nimg * a.H + iy0) * a.W + ix0) * a.ldx + a.xoff + 4 * g0;
+    // B slots: slot = tid + 256 i -> (k row, column group of 4); 12 groups per row
+    int boff[BPT], bdst[BPT];
+#pragma unroll
+    for (int i = 0; i < BPT; i++) {
+        const int slot = tid + 256 * i, kk = slot / (BN / 4), n4 = slot - kk * (BN / 4);
+        boff[i] = kk * a.ldw + 4 * n4;
+        bdst[i] = kk * BN + 4 * n4;
+    }
+
+    float4 areg[APT];
+    float4 breg[BPT];
+    int ky = 0, kx = 0, c0 = 0, k0 = 0;
+    auto load_chunk = [&]() {
+        const int soff = (ky * a.W + kx) * a.ldx + c0;
+        bool inside = true;
+        if (PAD) inside = (unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W;
+#pragma unroll
+        for (int i = 0; i < APT; i++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((ASLOTS % 256 == 0 || tid + i * 256 < ASLOTS) && inside)
+                v = *reinterpret_cast<const float4*>(a.x + (aoff + soff + 4 * GSTEP * i));
+            areg[i] = v;
+        }
+        const float* wrow = a.w + (size_t)k0 * a.ldw;
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BSLOTS % 256 == 0 || tid + i * 256 < BSLOTS) v = *reinterpret_cast<const float4*>(wrow + boff[i]);
+            breg[i] = v;
+        }
+        k0 += BK; c0 += BK;
+        if (c0 >= a.Cin) { c0 = 0; if (++kx == a.KW) { kx = 0; ++ky; } }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < APT; i++) {
+            if (ASLOTS % 256 == 0 || tid + i * 256 < ASLOTS) {
+                const int g = g0 + GSTEP * i;
+                As[(4 * g + 0) * BM + row] = areg[i].x;
+                As[(4 * g + 1) * BM + row] = areg[i].y;
+                As[(4 * g + 2) * BM + row] = areg[i].z;
+                As[(4 * g + 3) * BM + row] = areg[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; i++) {
+            if (BSLOTS % 256 == 0 || tid + i * 256 < BSLOTS) *reinterpret_cast<float4*>(&Bs[bdst[i]]) = breg[i];
+        }
+    };
+
+    f32x4t acc[2][3];
+#pragma unroll
+    for (int tn = 0; tn < 3; tn++) {
+        const float b = a.bias != nullptr ? a.bias[tn * 16 + l15] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) acc[tm][tn] = f32x4t{b, b, b, b};
+    }
+
+    const int nchunks = a.K / BK;
+    load_chunk();
+    for (int ch = 0; ch < nchunks; ch++) {
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk();
+#pragma unroll
+        for (int s = 0; s < BK / 4; s++) {
+            float av[2], bv[3];
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++) av[tm] = As[(4 * s + kq) * BM + wave * 32 + tm * 16 + l15];
+#pragma unroll
+            for (int tn = 0; tn < 3; tn++) bv[tn] = Bs[(4 * s + kq) * BN + tn * 16 + l15];
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 3; tn++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int tn = 0; tn < 3; tn++) {
+        const int n = tn * 16 + l15;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        const float sf = a.scale ? a.shift[n] : 0.f;
+        const float sl = a.act == TRL_ACT_PRELU ? a.slope[n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int mr = m0 + wave * 32 + tm * 16 + kq * 4 + q;
+                if (mr >= a.M) continue;
+                float v = acc[tm][tn][q];
+                if (a.scale) v = __builtin_fmaf(v, sc, sf);
+                if (a.res) {
+                    v = v * a.res_scale;
+                    v = v + a.res[(size_t)mr * a.ldres + n];
+                }
+                if (a.act == TRL_ACT_RELU) v = v > 0.f ? v : 0.f;
+                else if (a.act == TRL_ACT_PRELU) v = v > 0.f ? v : sl * v;
+                a.y[(size_t)mr * a.ldy + a.yoff + n] = v;
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 int launch_tap(const ConvArgs& a, dim3 grid, hipStream_t s) {
     if (a.ph || a.pw) conv_tap<BM, BN, WM, WN, BK, true><<<grid, 256, 0, s>>>(a);
@@ -761,6 +896,18 @@ int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
     // Deep K chunks (BK = 64) when K is long: a chunk's MFMAs (BK/2 x 64 cycles per wave tile) must cover
     // the global-load round trip of the next chunk, the only latency hiding a lone workgroup per CU has.
     const bool deep = a.K >= 192;
+    {   // Cout == 48 with whole-tap chunks: the 128 x 48 tile (no padded MFMA columns)
+        static const bool tap_off = getenv("TRL_NO_TAP") != nullptr;
+        const bool small = (long long)a.N * a.H * a.W * a.ldx + a.xoff < 0x7fffffffll && (long long)a.K * a.ldw < 0x7fffffffll;
+        if (vec && !tap_off && small && a.Cout == 48 && a.ldw >= 48 && a.M >= 16384 && a.K == a.KH * a.KW * a.Cin && (a.Cin % 28 == 0 || a.Cin % 32 == 0)) {
+            dim3 grid((a.M + 127) / 128, 1);
+            const bool pad = a.ph || a.pw;
+            if (a.Cin % 32 == 0) { if (pad) conv_tap48<32, true><<<grid, 256, 0, s>>>(a); else conv_tap48<32, false><<<grid, 256, 0, s>>>(a); }
+            else { if (pad) conv_tap48<28, true><<<grid, 256, 0, s>>>(a); else conv_tap48<28, false><<<grid, 256, 0, s>>>(a); }
+            TRL_LAUNCH_CHECK();
+            return TRL_OK;
+        }
+    }
     if (a.Cout <= 32) return deep ? launch_cfg<128, 32, 4, 1, 64>(a, vec, s) : launch_cfg<128, 32, 4, 1, 16>(a, vec, s);
     if (a.M >= 16384) return deep ? launch_cfg<128, 64, 2, 2, 32>(a, vec, s) : launch_cfg<128, 64, 2, 2, 16>(a, vec, s);
     if (a.M >= 1024) return deep ? launch_cfg<64, 64, 2, 2, 64>(a, vec, s) : launch_cfg<64, 64, 2, 2, 16>(a, vec, s);
