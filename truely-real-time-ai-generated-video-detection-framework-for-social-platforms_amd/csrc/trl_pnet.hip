@@ -60,6 +60,7 @@ struct PLevel {
     int khA, kwA, khmax, kwmax;   // adaptive-pool bins of the level are khA or khA+1 rows (kwA / kwA+1 columns)
     float rkh[2], rkw[2];    // RN(1/khA), RN(1/(khA+1)), same for kw: reciprocal division (see pyr_div)
     int fastdiv;             // bin sizes small enough for the exhaustively verified reciprocal division
+    unsigned vmA[4], vmB[4]; // mode 0: valid-byte masks of the 4 re-aligned dwords of a row for bins kwA / kwA+1 wide
     unsigned hmagic;         // ceil(2^32 / h); with wmagic: bin edges by multiply-high when 'arith' (no table load in the
     int arith;               // dependent-latency chain of a pixel): requires H*h*h < 2^32 and W*w*w < 2^32
     float scale;
@@ -276,10 +277,10 @@ __device__ __forceinline__ void pyr_level0(const uint8_t* __restrict__ frames, c
                 const uint32_t ty = tab[g.ytab0 + oy], tx = tab[g.xtab0 + ox];
                 ys = ty & 0xFFFF; kh = (int)(ty >> 16) - ys; xs = tx & 0xFFFF; kw = (int)(tx >> 16) - xs;
             }
-            const int nbytes = kw * 3;
             const unsigned lo0 = (unsigned)(ys * row_bytes + xs * 3 + fb3);        // byte offset from fptr of the bin's first byte
-            const unsigned vm0 = valid_bytes(0, nbytes), vm1 = valid_bytes(4, nbytes), vm2 = valid_bytes(8, nbytes),
-                           vm3 = valid_bytes(12, nbytes);
+            const bool wA = kw == g.kwA;                                      // a level has two bin widths: pick, don't compute
+            const unsigned vm0 = wA ? g.vmA[0] : g.vmB[0], vm1 = wA ? g.vmA[1] : g.vmB[1], vm2 = wA ? g.vmA[2] : g.vmB[2],
+                           vm3 = wA ? g.vmA[3] : g.vmB[3];
             // the aligned 16/20-byte fetch of the LAST row may run past the end of the frame buffer only for the very
             // last pixels of the last frame: those take per-dword clamped loads
             const bool safe = !lastf || (lo0 & ~3u) + (unsigned)((kh - 1) * row_bytes) + 4u * ndw <= avail;
@@ -746,6 +747,10 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
         p.rkh[0] = 1.0f / (float)p.khA; p.rkh[1] = 1.0f / (float)(p.khA + 1);
         p.rkw[0] = 1.0f / (float)p.kwA; p.rkw[1] = 1.0f / (float)(p.kwA + 1);
         p.fastdiv = (p.khA + 1 <= 96 && p.kwA + 1 <= 96) ? 1 : 0;
+        for (int d = 0; d < 4; d++) {
+            auto vb = [](int rel, int nbytes) { int hi = nbytes - rel; hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi); return hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u); };
+            p.vmA[d] = vb(4 * d, 3 * p.kwA); p.vmB[d] = vb(4 * d, 3 * (p.kwA + 1));
+        }
         p.wmagic = (unsigned)((0x100000000ull + g.w - 1) / g.w);
         p.hmagic = (unsigned)((0x100000000ull + g.h - 1) / g.h);
         // floor(n / d) == umulhi(n, ceil(2^32 / d)) for every n with n * d < 2^32 (n <= (in + 1) * out here)
