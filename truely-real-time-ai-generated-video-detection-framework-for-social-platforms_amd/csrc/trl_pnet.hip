@@ -805,6 +805,206 @@ size_t trl_pnet_fused_bytes(trl_ctx* c, int n, int H, int W) {
 
 // All pyramid levels of all n frames: pyramid kernel + one persistent fused launch.
 // ev[0..1] bracket the pyramid kernel, ev[2..3] the fused kernel (HIP events on the same stream).
+namespace {
+
+// ---- coarse levels in ONE streaming pass ------------------------------------------------------------------
+// The per-level kernels above make every level re-read its whole source chunk; for the coarse levels (bins wider than
+// 5 px: 8 of the 11 levels at 720p, 15 % of the pixels) that re-read IS the cost (~55 us per level and 64 frames,
+// whatever the level's size).  k_pyramid_stream reads each source row ONCE for all of them:
+//   * a workgroup owns a band of the frame (rows [R0,R1) x a column band of <= 4096 bytes) and walks its rows top down;
+//     thread t owns 16 consecutive bytes of the row (one dword-aligned 16-byte load + 1 dword, re-aligned by a scalar shift);
+//   * per level it keeps the column sums of the current output row's bin in registers (16 byte-columns, packed 16-bit);
+//     at the bin's last source row the sums go to LDS, the horizontal bins are reduced, normalised (pyr_norm) and stored,
+//     and the accumulators restart (with the current row when consecutive bins share it);
+//   * a band computes the bins that START inside it and reads on past its end until they are complete (no atomics).
+// Integer sums in any order are exact, so the result is bit-identical to the per-level kernels (tests: every level, 180p..4K).
+constexpr int SMAXL = 12;               // coarse levels per launch
+constexpr int SBYTES = 4096;            // bytes of a source row a workgroup covers (256 threads x 16)
+struct SLevel { int h, w, pix0, pix_pad, ytab0, xtab0, khA, kwA, fastdiv; float rkh[2], rkw[2]; };
+struct PyrStreamArgs {
+    int H, W, n_frames, f0, nlev, rows_per_band, cols_per_band, row_bands, col_bands;
+    long long pyr_stride;
+    SLevel lv[SMAXL];
+};
+
+__device__ __forceinline__ float stream_norm(unsigned s, int kh, int kw, const SLevel& g) {
+    const float a = (float)s, fkh = (float)kh, fkw = (float)kw;
+    float q;
+    if (g.fastdiv) {
+        const float r1 = kh == g.khA ? g.rkh[0] : g.rkh[1], r2 = kw == g.kwA ? g.rkw[0] : g.rkw[1];
+        q = pyr_div(pyr_div(a, fkh, r1), fkw, r2);
+    } else {
+        q = a / fkh / fkw;
+    }
+    return (q - 127.5f) * 0.0078125f;
+}
+
+constexpr int STAB = 6144;              // bin-edge words of the coarse levels kept in LDS (rows + columns of every level)
+template <int NL>
+__global__ __launch_bounds__(256) void k_pyramid_stream(const uint8_t* __restrict__ frames, PyrStreamArgs a, const uint32_t* __restrict__ gtab,
+                                                        float4* __restrict__ pyr) {
+    __shared__ unsigned colbuf[SBYTES];
+    __shared__ uint32_t tab[STAB];          // the levels' edge tables, re-based: level l rows at ty0[l], columns at tx0[l]
+    const int tid = threadIdx.x;
+    const int f = a.f0 + blockIdx.y;
+    const int rb = blockIdx.x / a.col_bands, cb = blockIdx.x - rb * a.col_bands;
+    const int R0 = rb * a.rows_per_band, R1 = (R0 + a.rows_per_band < a.H) ? R0 + a.rows_per_band : a.H;
+    const int C0 = cb * a.cols_per_band, C1 = (C0 + a.cols_per_band < a.W) ? C0 + a.cols_per_band : a.W;
+    const int row_bytes = a.W * 3;
+    const long long fbase = (long long)f * a.H * row_bytes;
+    const long long last_dw = ((long long)a.n_frames * a.H * row_bytes - 1) >> 2;
+    const uint32_t* base32 = reinterpret_cast<const uint32_t*>(frames);
+    // edge tables of the handled levels -> LDS (a flush would otherwise end in a dependent global load)
+    int ty0[NL], tx0[NL];
+    {
+        int pos = 0;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            ty0[l] = tx0[l] = 0;
+            if (l < a.nlev) {
+                const SLevel& g = a.lv[l];
+                ty0[l] = pos; tx0[l] = pos + g.h;
+                for (int i = tid; i < g.h; i += 256) tab[pos + i] = gtab[g.ytab0 + i];
+                for (int i = tid; i < g.w; i += 256) tab[pos + g.h + i] = gtab[g.xtab0 + i];
+                pos += g.h + g.w;
+            }
+        }
+    }
+    __syncthreads();
+
+    // per level (all scalar): owned output rows [j, jend), owned output columns [ox0, ox1), current bin rows [ys, ye)
+    int j[NL], jend[NL], ys[NL], ye[NL], ox0[NL], ox1[NL];
+    int yend = R0;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        j[l] = jend[l] = 0; ys[l] = ye[l] = 0x7fffffff; ox0[l] = ox1[l] = 0;
+        if (l < a.nlev) {
+            const SLevel& g = a.lv[l];
+            auto first_at_or_after = [&](int tab0, int n_out, int n_in, int pos) {   // first bin whose start >= pos
+                if (pos >= n_in) return n_out;
+                int q = (int)(((long long)pos * n_out + n_in - 1) / n_in);
+                if (q > n_out) q = n_out;
+                while (q > 0 && (int)(tab[tab0 + q - 1] & 0xFFFF) >= pos) q--;
+                while (q < n_out && (int)(tab[tab0 + q] & 0xFFFF) < pos) q++;
+                return q;
+            };
+            j[l] = first_at_or_after(ty0[l], g.h, a.H, R0);
+            jend[l] = first_at_or_after(ty0[l], g.h, a.H, R1);
+            ox0[l] = first_at_or_after(tx0[l], g.w, a.W, C0);
+            ox1[l] = first_at_or_after(tx0[l], g.w, a.W, C1);
+            if (j[l] < jend[l] && ox0[l] < ox1[l]) {
+                const uint32_t t0 = tab[ty0[l] + j[l]], t1 = tab[ty0[l] + jend[l] - 1];
+                ys[l] = t0 & 0xFFFF; ye[l] = t0 >> 16;
+                yend = ((int)(t1 >> 16) > yend) ? (int)(t1 >> 16) : yend;
+            } else {
+                j[l] = jend[l];
+            }
+        }
+    }
+    // zero the 64-pixel padding behind each level once per frame
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+            if (l < a.nlev) {
+                const SLevel& g = a.lv[l];
+                for (int p = g.h * g.w + tid; p < g.pix_pad; p += 256)
+                    pyr_store(pyr + ((long long)f * a.pyr_stride + g.pix0 + p), make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+    }
+    if (yend <= R0) return;
+
+    unsigned ev[NL][4], od[NL][4];          // packed 16-bit column sums: bytes 0,2 / 1,3 of each of the thread's 4 dwords
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) { ev[l][d] = 0; od[l][d] = 0; }
+
+    // one source row: this thread's 16 bytes at byte offset C0*3 + 16*tid of row y
+    auto load_row = [&](int y, unsigned (&w)[5], unsigned& sh) {
+        const int yy = y < a.H ? y : a.H - 1;                                    // rows past the frame are never accumulated
+        const long long o = fbase + (long long)yy * row_bytes + (long long)C0 * 3;   // scalar
+        sh = (unsigned)(o & 3);
+        const long long dw = (o >> 2) + 4 * tid;
+        if (dw + 4 <= last_dw) {
+            const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(base32 + dw);
+            w[0] = v4[0]; w[1] = v4[1]; w[2] = v4[2]; w[3] = v4[3];
+            w[4] = base32[dw + 4];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) w[k] = base32[dw + k <= last_dw ? dw + k : last_dw];
+        }
+    };
+    auto consume = [&](int y, const unsigned (&w)[5], unsigned sh) {
+        unsigned v[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) v[d] = __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh);
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            if (l < a.nlev && y >= ys[l] && y < ye[l]) {                         // uniform
+#pragma unroll
+                for (int d = 0; d < 4; d++) { ev[l][d] += v[d] & 0x00FF00FFu; od[l][d] += (v[d] >> 8) & 0x00FF00FFu; }
+                if (y == ye[l] - 1) {
+                    // ---- the bin row is complete: column sums -> LDS -> horizontal bins -> normalise -> store ----
+                    const SLevel& g = a.lv[l];
+                    const int kh = ye[l] - ys[l];
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        colbuf[16 * tid + 4 * d + 0] = ev[l][d] & 0xFFFFu; colbuf[16 * tid + 4 * d + 1] = od[l][d] & 0xFFFFu;
+                        colbuf[16 * tid + 4 * d + 2] = ev[l][d] >> 16;     colbuf[16 * tid + 4 * d + 3] = od[l][d] >> 16;
+                    }
+                    __syncthreads();
+                    for (int ox = ox0[l] + tid; ox < ox1[l]; ox += 256) {
+                        const uint32_t tx = tab[tx0[l] + ox];
+                        const int xs = tx & 0xFFFF, xe = tx >> 16;
+                        unsigned s0 = 0, s1 = 0, s2 = 0;
+                        for (int xx = xs; xx < xe; xx++) {
+                            const unsigned* p = colbuf + (xx - C0) * 3;
+                            s0 += p[0]; s1 += p[1]; s2 += p[2];
+                        }
+                        float4 o4;
+                        o4.x = stream_norm(s0, kh, xe - xs, g); o4.y = stream_norm(s1, kh, xe - xs, g); o4.z = stream_norm(s2, kh, xe - xs, g);
+                        o4.w = 0.f;
+                        pyr_store(pyr + ((long long)f * a.pyr_stride + g.pix0 + (long long)j[l] * g.w + ox), o4);
+                    }
+                    __syncthreads();
+                    // next owned bin of this level; consecutive bins may share this source row
+                    j[l]++;
+                    if (j[l] < jend[l]) {
+                        const uint32_t t0 = tab[ty0[l] + j[l]];
+                        ys[l] = t0 & 0xFFFF; ye[l] = t0 >> 16;
+                    } else {
+                        ys[l] = ye[l] = 0x7fffffff;
+                    }
+                    const bool again = ys[l] <= y;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        ev[l][d] = again ? (v[d] & 0x00FF00FFu) : 0u;
+                        od[l][d] = again ? ((v[d] >> 8) & 0x00FF00FFu) : 0u;
+                    }
+                }
+            }
+        }
+    };
+
+    // rows in groups of four: the loads of the next group are in flight while this one is consumed
+    unsigned wb[4][5], shb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) load_row(R0 + u, wb[u], shb[u]);
+    for (int y = R0; y < yend; y += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            unsigned wc[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) wc[k] = wb[u][k];
+            const unsigned shc = shb[u];
+            if (y + u + 4 < yend) load_row(y + u + 4, wb[u], shb[u]);
+            if (y + u < yend) consume(y + u, wc, shc);
+        }
+    }
+}
+
+}  // namespace
+
 // The pyramid of all n frames (production path of both the fused PNet and the debug export below).
 static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, PnetArgs& a, hipEvent_t* ev, hipStream_t s) {
     if (((uintptr_t)d_frames & 3) != 0) { trl_set_error("frame buffer must be 4-byte aligned"); return TRL_ERR_INVALID; }
@@ -830,9 +1030,46 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
     int chunk = chunk_env > 0 ? chunk_env : (int)((176ll << 20) / ((long long)H * W * 3));
     if (chunk < 1) chunk = 1;
     if (chunk > n) chunk = n;
+    // coarse levels: one streaming pass (k_pyramid_stream) when its preconditions hold, else the per-level kernels
+    static const bool stream_off = getenv("TRL_PYR_STREAM") && atoi(getenv("TRL_PYR_STREAM")) == 0;
+    PyrStreamArgs sa;
+    sa.nlev = 0;
+    int stab_words = 0;
+    bool stream_ok = !stream_off;
+    // which levels stream: by default the coarse ones (mode != 0); TRL_PYR_STREAM_FROM=k streams every level >= k
+    static const int from_env = getenv("TRL_PYR_STREAM_FROM") ? atoi(getenv("TRL_PYR_STREAM_FROM")) : -1;
+    bool streamed[16] = {};
+    for (int l = 0; l < a.L && stream_ok; l++) {
+        const PLevel& g = a.lv[l];
+        if (from_env >= 0 ? (l < from_env) : (g.mode == 0)) continue;
+        streamed[l] = true;
+        if (sa.nlev >= SMAXL || g.khmax > 256 || (g.kwmax + 2) * 3 > SBYTES / 2) { stream_ok = false; break; }
+        stab_words += g.h + g.w;
+        SLevel& t = sa.lv[sa.nlev++];
+        t.h = g.h; t.w = g.w; t.pix0 = g.pix0; t.pix_pad = g.pix_pad; t.ytab0 = g.ytab0; t.xtab0 = g.xtab0; t.khA = g.khA; t.kwA = g.kwA;
+        t.fastdiv = g.fastdiv; t.rkh[0] = g.rkh[0]; t.rkh[1] = g.rkh[1]; t.rkw[0] = g.rkw[0]; t.rkw[1] = g.rkw[1];
+    }
+    if (stream_ok && sa.nlev > 0 && stab_words <= STAB && n <= 65535) {
+        int kwm = 0;
+        for (int l = 0; l < a.L; l++) if (streamed[l] && a.lv[l].kwmax > kwm) kwm = a.lv[l].kwmax;
+        sa.H = H; sa.W = W; sa.n_frames = n; sa.pyr_stride = a.pyr_stride;
+        if (W * 3 <= SBYTES) { sa.col_bands = 1; sa.cols_per_band = W; }
+        else { sa.cols_per_band = SBYTES / 3 - kwm - 2; sa.col_bands = (W + sa.cols_per_band - 1) / sa.cols_per_band; }
+        static const int bands_env = getenv("TRL_PYR_BANDS") ? atoi(getenv("TRL_PYR_BANDS")) : 0;
+        sa.row_bands = bands_env > 0 ? bands_env : (H >= 256 ? 3 : 1);
+        sa.rows_per_band = (H + sa.row_bands - 1) / sa.row_bands;
+        sa.f0 = 0;                                  // every source row is read once: no Infinity-Cache chunking needed
+        const dim3 sgrid(sa.row_bands * sa.col_bands, n);
+        if (sa.nlev <= 8) k_pyramid_stream<8><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
+        else k_pyramid_stream<SMAXL><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
+        TRL_LAUNCH_CHECK();
+    } else {
+        stream_ok = false;
+    }
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int nf = (n - f0 < chunk) ? n - f0 : chunk;
         for (int l = 0; l < a.L; l++) {
+            if (stream_ok && streamed[l]) continue;
             PyrArgs pa;
             pa.H = H; pa.W = W; pa.n_frames = n; pa.f0 = f0; pa.pyr_stride = a.pyr_stride; pa.g = a.lv[l];
             const int threads = pa.g.pix_pad << pa.g.gshift;
