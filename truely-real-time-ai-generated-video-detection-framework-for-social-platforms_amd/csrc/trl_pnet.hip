@@ -1031,41 +1031,49 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
     if (chunk < 1) chunk = 1;
     if (chunk > n) chunk = n;
     // coarse levels: one streaming pass (k_pyramid_stream) when its preconditions hold, else the per-level kernels
+    // Streaming pass (k_pyramid_stream) for the coarse levels (mode != 0); optionally (TRL_PYR_STREAM_FINE=1) a second one for
+    // the fine levels.  A group that does not meet the kernel's preconditions falls back to the per-level kernels below.
     static const bool stream_off = getenv("TRL_PYR_STREAM") && atoi(getenv("TRL_PYR_STREAM")) == 0;
-    PyrStreamArgs sa;
-    sa.nlev = 0;
-    int stab_words = 0;
-    bool stream_ok = !stream_off;
-    // which levels stream: by default the coarse ones (mode != 0); TRL_PYR_STREAM_FROM=k streams every level >= k
-    static const int from_env = getenv("TRL_PYR_STREAM_FROM") ? atoi(getenv("TRL_PYR_STREAM_FROM")) : -1;
+    static const bool fine_on = getenv("TRL_PYR_STREAM_FINE") && atoi(getenv("TRL_PYR_STREAM_FINE")) != 0;   // measured: 1.75 vs 1.83 ms, not worth a default
+    static const int bands_env = getenv("TRL_PYR_BANDS") ? atoi(getenv("TRL_PYR_BANDS")) : 0;
+    static const int fbands_env = getenv("TRL_PYR_FINE_BANDS") ? atoi(getenv("TRL_PYR_FINE_BANDS")) : 0;
     bool streamed[16] = {};
-    for (int l = 0; l < a.L && stream_ok; l++) {
-        const PLevel& g = a.lv[l];
-        if (from_env >= 0 ? (l < from_env) : (g.mode == 0)) continue;
-        streamed[l] = true;
-        if (sa.nlev >= SMAXL || g.khmax > 256 || (g.kwmax + 2) * 3 > SBYTES / 2) { stream_ok = false; break; }
-        stab_words += g.h + g.w;
-        SLevel& t = sa.lv[sa.nlev++];
-        t.h = g.h; t.w = g.w; t.pix0 = g.pix0; t.pix_pad = g.pix_pad; t.ytab0 = g.ytab0; t.xtab0 = g.xtab0; t.khA = g.khA; t.kwA = g.kwA;
-        t.fastdiv = g.fastdiv; t.rkh[0] = g.rkh[0]; t.rkh[1] = g.rkh[1]; t.rkw[0] = g.rkw[0]; t.rkw[1] = g.rkw[1];
-    }
-    if (stream_ok && sa.nlev > 0 && stab_words <= STAB && n <= 65535) {
-        int kwm = 0;
-        for (int l = 0; l < a.L; l++) if (streamed[l] && a.lv[l].kwmax > kwm) kwm = a.lv[l].kwmax;
+    auto stream_group = [&](bool fine, int row_bands) -> int {
+        PyrStreamArgs sa;
+        sa.nlev = 0;
+        int stab_words = 0, kwm = 0;
+        bool picked[16] = {};
+        for (int l = 0; l < a.L; l++) {
+            const PLevel& g = a.lv[l];
+            if ((g.mode == 0) != fine) continue;
+            if (sa.nlev >= SMAXL || g.khmax > 256 || (g.kwmax + 2) * 3 > SBYTES / 2) return TRL_OK;      // group not streamable
+            picked[l] = true;
+            stab_words += g.h + g.w;
+            kwm = g.kwmax > kwm ? g.kwmax : kwm;
+            SLevel& t = sa.lv[sa.nlev++];
+            t.h = g.h; t.w = g.w; t.pix0 = g.pix0; t.pix_pad = g.pix_pad; t.ytab0 = g.ytab0; t.xtab0 = g.xtab0; t.khA = g.khA; t.kwA = g.kwA;
+            t.fastdiv = g.fastdiv; t.rkh[0] = g.rkh[0]; t.rkh[1] = g.rkh[1]; t.rkw[0] = g.rkw[0]; t.rkw[1] = g.rkw[1];
+        }
+        if (sa.nlev == 0 || stab_words > STAB || n > 65535) return TRL_OK;
         sa.H = H; sa.W = W; sa.n_frames = n; sa.pyr_stride = a.pyr_stride;
         if (W * 3 <= SBYTES) { sa.col_bands = 1; sa.cols_per_band = W; }
         else { sa.cols_per_band = SBYTES / 3 - kwm - 2; sa.col_bands = (W + sa.cols_per_band - 1) / sa.cols_per_band; }
-        static const int bands_env = getenv("TRL_PYR_BANDS") ? atoi(getenv("TRL_PYR_BANDS")) : 0;
-        sa.row_bands = bands_env > 0 ? bands_env : (H >= 256 ? 3 : 1);
+        sa.row_bands = H >= 256 ? row_bands : 1;
         sa.rows_per_band = (H + sa.row_bands - 1) / sa.row_bands;
         sa.f0 = 0;                                  // every source row is read once: no Infinity-Cache chunking needed
         const dim3 sgrid(sa.row_bands * sa.col_bands, n);
-        if (sa.nlev <= 8) k_pyramid_stream<8><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
+        if (sa.nlev <= 4) k_pyramid_stream<4><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
+        else if (sa.nlev <= 8) k_pyramid_stream<8><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
         else k_pyramid_stream<SMAXL><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
         TRL_LAUNCH_CHECK();
-    } else {
-        stream_ok = false;
+        for (int l = 0; l < a.L; l++) streamed[l] = streamed[l] || picked[l];
+        return TRL_OK;
+    };
+    if (!stream_off) {
+        TRL_CHECK(stream_group(false, bands_env > 0 ? bands_env : 3));
+        if (fine_on) TRL_CHECK(stream_group(true, fbands_env > 0 ? fbands_env : 8));
     }
+    const bool stream_ok = true;
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int nf = (n - f0 < chunk) ? n - f0 : chunk;
         for (int l = 0; l < a.L; l++) {
