@@ -139,6 +139,9 @@ int  trl_debug_crop_resize(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, 
  * out[0] = PNet kernel (fused: the one persistent launch; generic: sum over levels),
  * out[1] = whole call, out[2] = number of PNet launches timed, out[3] = pyramid kernel. */
 int  trl_debug_timings(trl_ctx* ctx, float* out4);
+/* execution span (first workgroup start -> last workgroup end, device wall clock) of the last fused PNet launch, in ms:
+ * the kernel's duration as rocprofv3 reports it, free of stream-queueing time when several contexts share the GPU */
+int  trl_debug_pnet_kernel_ms(trl_ctx* ctx, float* ms);
 
 #ifdef __cplusplus
 }

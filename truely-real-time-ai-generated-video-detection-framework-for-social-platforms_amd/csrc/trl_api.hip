@@ -45,6 +45,8 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
     TRL_HIP(hipSetDevice(cfg->device));
     trl_ctx* c = new trl_ctx();
     c->cfg = *cfg;
+    if (hipMalloc((void**)&c->pnet_clk, 16) != hipSuccess) c->pnet_clk = nullptr;
+    TRL_HIP(hipMalloc((void**)&c->pnet_cursor, 64));
     if (hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess) { delete c; trl_set_error("hipHostMalloc failed"); return TRL_ERR_HIP; }
     memset(c->h_pinned, 0, 256);
     (void)hipEventCreate(&c->ev_call0);
@@ -63,6 +65,8 @@ int trl_destroy(trl_ctx* c) {
     if (c->scratch.base) (void)hipFree(c->scratch.base);
     if (c->sims_tmp.base) (void)hipFree(c->sims_tmp.base);
     if (c->pyr_tab) (void)hipFree(c->pyr_tab);
+    if (c->pnet_clk) (void)hipFree(c->pnet_clk);
+    if (c->pnet_cursor) (void)hipFree(c->pnet_cursor);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);
     if (c->ev_call1) (void)hipEventDestroy(c->ev_call1);
@@ -284,6 +288,14 @@ static void collect_timings(trl_ctx* c) {
         launches = c->pnet_ev_used;
     }
     c->last_ms[0] = pnet_ms; c->last_ms[1] = call_ms; c->last_ms[2] = (float)launches; c->last_ms[3] = pyr_ms;
+    c->pnet_kernel_ms = 0.f;
+    if (c->cfg.pnet_mode == 0 && c->pnet_clk) {
+        unsigned long long t[2] = {0, 0};
+        int khz = 0;
+        if (hipMemcpy(t, c->pnet_clk, sizeof t, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device) == hipSuccess && khz > 0 && t[1] > t[0])
+            c->pnet_kernel_ms = (float)((double)(t[1] - t[0]) / (double)khz);
+    }
 }
 
 extern "C" {
@@ -448,6 +460,12 @@ int trl_debug_crop_resize(trl_ctx* c, const uint8_t* d_frames, int n, int H, int
     if (!c || !d_frames || !d_rect || !d_valid || !d_faces || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
     return trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, d_faces, (hipStream_t)stream);
 }
+int trl_debug_pnet_kernel_ms(trl_ctx* c, float* ms) {
+    if (!c || !ms) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
+    *ms = c->pnet_kernel_ms;
+    return TRL_OK;
+}
+
 int trl_debug_timings(trl_ctx* c, float* out4) {
     if (!c || !out4) return TRL_ERR_INVALID;
     out4[0] = c->last_ms[0]; out4[1] = c->last_ms[1]; out4[2] = c->last_ms[2]; out4[3] = c->last_ms[3];

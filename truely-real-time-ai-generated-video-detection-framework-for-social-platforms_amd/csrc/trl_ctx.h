@@ -49,6 +49,9 @@ struct trl_ctx {
     float last_ms[4] = {0, 0, 0, 0};
     int pnet_mono1 = 0;              // conv1 PReLU slopes all >= 0
     int pnet_unit = 0;               // every PNet PReLU slope in [0, 1]
+    int32_t* pnet_cursor = nullptr;           // device: 8 per-XCD tile cursors of the fused PNet launch
+    unsigned long long* pnet_clk = nullptr;   // device: first-start / last-end wall clock of the fused PNet launch
+    float pnet_kernel_ms = 0.f;      // its span in ms (collect_timings)
     int dbg_poison = -1;             // >= 0 after trl_debug_poison: byte written into every newly allocated workspace
     int rnet_front_mode = -1, onet_front_mode = -1;   // conv1 PReLU slope class (trl_front.hip), -1 = not yet classified
     uint32_t* pyr_tab = nullptr;     // pyramid bin-edge tables for the last (H, W)

@@ -77,6 +77,8 @@ struct PnetArgs {
     int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); 0 in production
     int mono1;                                 // all conv1 PReLU slopes >= 0 (pool/PReLU may be swapped)
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
+    int32_t* xcd_next;                         // per-XCD dynamic tile cursor (8 counters, zeroed before the launch)
+    unsigned long long* clk;                   // [0] = earliest workgroup start, [1] = latest workgroup end (device wall clock)
 };
 
 // ---- pyramid -------------------------------------------------------------------------------------
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every M-tile index below is SALU work
+    if (tid == 0 && a.clk) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());   // execution span of the launch, queueing excluded
     const int l15 = lane & 15, kq = lane >> 4;      // 16x16x4 operand coordinates
     const int l31 = lane & 31, hh = lane >> 5;      // 32x32x2 operand coordinates
 
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 
     const int total_tiles = a.tiles_per_frame * a.n_frames;
     // XCD-aware persistent schedule: blocks sharing blockIdx%8 (one XCD) walk one contiguous 1/8 of the tiles
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
     const int chunk = (total_tiles + 7) / 8;
     const int t_begin = xcd * chunk, t_end = (t_begin + chunk < total_tiles) ? t_begin + chunk : total_tiles;
 
@@ -462,13 +465,22 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         }
     };
     float* const HS = HSall + wave * 32 * 9;
-    int tile = t_begin + slot;
+    // Dynamic schedule inside the XCD's chunk: a workgroup takes the next tile of its XCD from an atomic cursor, so one that
+    // starts late (another stream's kernel still on its CU) or loses time simply processes fewer tiles; the cursor value for
+    // tile i+1 is fetched at the top of tile i and travels through LDS (the loop's own barriers order it).
+    __shared__ int next_tile_s;
+    if (tid == 0) next_tile_s = t_begin + atomicAdd(&a.xcd_next[xcd], 1);
+    __syncthreads();
+    int tile = __builtin_amdgcn_readfirstlane(next_tile_s);
+    __syncthreads();
     TileId cur = decode(tile < t_end ? tile : 0), nxt = cur;
     if (tile < t_end) issue_input(cur);
-    int rot = 0;
-    for (; tile < t_end; tile += per_xcd_blocks, cur = nxt, rot++) {
+    int rot = 0, tile_nxt = tile;
+    for (; tile < t_end; tile = tile_nxt, cur = nxt, rot++) {
         const int f = cur.f, l = cur.l, ty = cur.ty, tx = cur.tx;
         const PLevel& g = a.lv[l];
+        int cursor = 0;
+        if (tid == 0) cursor = atomicAdd(&a.xcd_next[xcd], 1);   // in flight during phases 0-1, published before phase 2
 
         // ---- phase 0: prefetched input tile -> RA as [42][42][3] ---------------------------------------------
 #pragma unroll
@@ -552,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             else if (mono) conv1_pool(std::integral_constant<int, 1>{});
             else conv1_pool(std::integral_constant<int, 0>{});
         }
+        if (tid == 0) next_tile_s = t_begin + cursor;
         __syncthreads();
 
         // ---- phase 2: conv2 + PReLU -> RA as [324][17] ---------------------------------------------------------
@@ -609,7 +622,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         __syncthreads();
 
         // next tile's input: global loads into registers only (RA is still read by phase 3)
-        if (tile + per_xcd_blocks < t_end) { nxt = decode(tile + per_xcd_blocks); issue_input(nxt); }
+        tile_nxt = __builtin_amdgcn_readfirstlane(next_tile_s);
+        if (tile_nxt < t_end) { nxt = decode(tile_nxt); issue_input(nxt); }
 
         // ---- phase 3: conv3 + PReLU -> per-wave staging -> heads -> candidates -------------------------------
         if (!(a.dbg_skip & 8)) {
@@ -696,6 +710,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         }
         __syncthreads();   // RA / RB are rewritten by the next tile
     }
+    if (tid == 0 && a.clk) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
 
 }  // namespace
@@ -794,6 +809,8 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
     { const char* e = getenv("TRL_PNET_SKIP"); a.dbg_skip = e ? atoi(e) : 0; }
     a.mono1 = c->pnet_mono1;
     a.lvl_cnt = c->cb.lvl_cnt; a.lvl_rec = c->cb.lvl_rec; a.flags = c->cb.flags;
+    a.clk = c->pnet_clk;
+    a.xcd_next = c->pnet_cursor;
     return TRL_OK;
 }
 
@@ -1118,6 +1135,11 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     int grid = 256 * 2;                       // 2 resident workgroups per CU (<= 256 VGPRs)
     if (grid > ((total_tiles + 7) / 8) * 8) grid = ((total_tiles + 7) / 8) * 8;
     if (grid < 8) grid = 8;
+    TRL_HIP(hipMemsetAsync(c->pnet_cursor, 0, 8 * sizeof(int32_t), s));
+    if (c->pnet_clk) {   // device-clock span of the launch (what rocprofv3 reports as the kernel's duration)
+        TRL_HIP(hipMemsetAsync(c->pnet_clk, 0xFF, 8, s));
+        TRL_HIP(hipMemsetAsync(c->pnet_clk + 1, 0, 8, s));
+    }
     if (c->pnet_unit) k_pnet_fused<true><<<grid, 256, 0, s>>>(a);
     else k_pnet_fused<false><<<grid, 256, 0, s>>>(a);
     TRL_LAUNCH_CHECK();

@@ -194,7 +194,9 @@ class Engine:
     def timings(self):
         t = (C.c_float * 4)()
         _lib.check(self.lib.trl_debug_timings(self._h, t))
-        return {"pnet_ms": t[0], "call_ms": t[1], "pnet_launches": int(t[2]), "pyramid_ms": t[3]}
+        k = C.c_float()
+        _lib.check(self.lib.trl_debug_pnet_kernel_ms(self._h, C.byref(k)))
+        return {"pnet_ms": t[0], "call_ms": t[1], "pnet_launches": int(t[2]), "pyramid_ms": t[3], "pnet_kernel_ms": float(k.value)}
 
 
 _default: Engine | None = None
