@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         const int f = cur.f, l = cur.l, ty = cur.ty, tx = cur.tx;
         const PLevel& g = a.lv[l];
         int cursor = 0;
-        if (tid == 0) cursor = atomicAdd(&a.xcd_next[xcd], 1);   // in flight during phases 0-1, published before phase 2
+        if (tid == 0) cursor = atomicAdd(&a.xcd_next[xcd], 1);   // in flight during phases 0-2, published at the barrier that ends phase 2
 
         // ---- phase 0: prefetched input tile -> RA as [42][42][3] ---------------------------------------------
 #pragma unroll
@@ -564,7 +564,6 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             else if (mono) conv1_pool(std::integral_constant<int, 1>{});
             else conv1_pool(std::integral_constant<int, 0>{});
         }
-        if (tid == 0) next_tile_s = t_begin + cursor;
         __syncthreads();
 
         // ---- phase 2: conv2 + PReLU -> RA as [324][17] ---------------------------------------------------------
@@ -619,6 +618,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 }
             }
         }
+        if (tid == 0) next_tile_s = t_begin + cursor;   // the cursor's atomic has had phases 0-2 to return
         __syncthreads();
 
         // next tile's input: global loads into registers only (RA is still read by phase 3)
