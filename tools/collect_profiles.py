@@ -34,7 +34,9 @@ def pmc_rows(path, counter):
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench.json"))
-    shutil.copy(os.path.join(SRC, "stats", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats.csv"))
+    shutil.copy(os.path.join(SRC, "stats2", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats.csv"))            # default command
+    shutil.copy(os.path.join(SRC, "stats", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats_inflight1.csv"))   # --in-flight 1
+    shutil.copy(os.path.join(SRC, "bench_inflight1.json"), os.path.join(DST, f"{tag}_bench_inflight1.json"))
     summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_summary.py"), os.path.join(SRC, "stats", "s_kernel_trace.csv")],
                           capture_output=True, text=True, check=True).stdout
     open(os.path.join(DST, f"{tag}_last_step_summary.txt"), "w").write(summ)
@@ -51,7 +53,7 @@ def main():
     hbm = (2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024.0
     traffic = {
         "kernel": "k_pnet_fused",
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 --no-cpu-baseline --in-flight 1",
         "FETCH_SIZE_KB_per_launch": per_launch["FETCH_SIZE"],
         "WRITE_SIZE_KB_per_launch": per_launch["WRITE_SIZE"],
         "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced 16 B/lane reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact",
