@@ -250,96 +250,114 @@ __device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ frames, co
 // VALU-bound, so everything per-row is pared down: the frame base is a scalar, the lane offset 32-bit; rows are
 // unrolled to the level's khmax (scalar) and only the last one can be dead; the byte masks of the two possible bin
 // widths are picked, not computed.
-template <typename A>
+// ROWS = the level's khmax (3..5), FOUR = bins reach 5 px (a 5th dword per row).  Two pixels per thread per pass: the row
+// loads of both are issued before either is consumed -- the kernel is bound by memory latency at 8 waves per SIMD, so
+// loads in flight per wave are what counts (specialising on ROWS / FOUR keeps it under 64 VGPRs).
+template <int ROWS, bool FOUR, typename A>
 __device__ __forceinline__ void pyr_level0(const uint8_t* __restrict__ frames, const A& a, const PLevel& g, const uint32_t* __restrict__ tab,
                                            float4* __restrict__ pyr, int f, int q0, int qstep) {
+    constexpr int ND = FOUR ? 5 : 4;                                                 // dwords fetched per row
     const long long fbase = (long long)f * a.H * a.W * 3;
     const long long total = (long long)a.n_frames * a.H * a.W * 3;
     const int fb3 = (int)(fbase & 3);
     const char* fptr = reinterpret_cast<const char*>(frames) + (fbase - fb3);     // dword aligned, scalar
     const int row_bytes = a.W * 3;
-    const bool four = g.nd > 3;
-    const unsigned ndw = four ? 5 : 4;                                               // dwords fetched per row
     const bool lastf = f == a.n_frames - 1;                                          // other frames may read into their successor
     const unsigned avail = ((unsigned)fb3 + (unsigned)a.H * row_bytes + 3u) & ~3u;  // bytes from fptr to the end of the last dword
-    for (int pixel = q0; pixel < g.pix_pad; pixel += qstep) {
-        const bool valid = pixel < g.h * g.w;
-        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) {
-            int oy = (int)__umulhi((unsigned)pixel, g.wmagic);       // floor(pixel / w) or one above it (large levels): fix up
-            oy -= (oy * g.w > pixel) ? 1 : 0;
-            const int ox = pixel - oy * g.w;
-            int ys, kh, xs, kw;
-            if (g.arith) {   // adaptive_avg_pool2d edges [floor(i*in/out), ceil((i+1)*in/out)) without touching memory
-                ys = (int)__umulhi((unsigned)(oy * a.H), g.hmagic);
-                kh = (int)__umulhi((unsigned)((oy + 1) * a.H + g.h - 1), g.hmagic) - ys;
-                xs = (int)__umulhi((unsigned)(ox * a.W), g.wmagic);
-                kw = (int)__umulhi((unsigned)((ox + 1) * a.W + g.w - 1), g.wmagic) - xs;
+    struct Px { unsigned ww[ROWS][ND]; unsigned shv[ROWS]; int kh, kw; bool valid; };
+    auto prep = [&](int pixel, Px& p) __attribute__((always_inline)) {
+        p.valid = pixel < g.h * g.w;
+        p.kh = 1; p.kw = 1;
+        if (!p.valid) return;
+        int oy = (int)__umulhi((unsigned)pixel, g.wmagic);       // floor(pixel / w) or one above it (large levels): fix up
+        oy -= (oy * g.w > pixel) ? 1 : 0;
+        const int ox = pixel - oy * g.w;
+        int ys, kh, xs, kw;
+        if (g.arith) {   // adaptive_avg_pool2d edges [floor(i*in/out), ceil((i+1)*in/out)) without touching memory
+            ys = (int)__umulhi((unsigned)(oy * a.H), g.hmagic);
+            kh = (int)__umulhi((unsigned)((oy + 1) * a.H + g.h - 1), g.hmagic) - ys;
+            xs = (int)__umulhi((unsigned)(ox * a.W), g.wmagic);
+            kw = (int)__umulhi((unsigned)((ox + 1) * a.W + g.w - 1), g.wmagic) - xs;
+        } else {
+            const uint32_t ty = tab[g.ytab0 + oy], tx = tab[g.xtab0 + ox];
+            ys = ty & 0xFFFF; kh = (int)(ty >> 16) - ys; xs = tx & 0xFFFF; kw = (int)(tx >> 16) - xs;
+        }
+        p.kh = kh; p.kw = kw;
+        const unsigned lo0 = (unsigned)(ys * row_bytes + xs * 3 + fb3);        // byte offset from fptr of the bin's first byte
+        // the aligned 16/20-byte fetch of the LAST row may run past the end of the frame buffer only for the very
+        // last pixels of the last frame: those take per-dword clamped loads
+        const bool safe = !lastf || (lo0 & ~3u) + (unsigned)((kh - 1) * row_bytes) + 4u * ND <= avail;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const unsigned lo = lo0 + (unsigned)((r < kh ? r : kh - 1) * row_bytes);
+            p.shv[r] = lo & 3u;
+            const char* q = fptr + (lo & ~3u);
+            if (safe) {
+                const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(q);
+                p.ww[r][0] = v4[0]; p.ww[r][1] = v4[1]; p.ww[r][2] = v4[2]; p.ww[r][3] = v4[3];
+                if (FOUR) p.ww[r][ND - 1] = *reinterpret_cast<const uint32_t*>(q + 16);
             } else {
-                const uint32_t ty = tab[g.ytab0 + oy], tx = tab[g.xtab0 + ox];
-                ys = ty & 0xFFFF; kh = (int)(ty >> 16) - ys; xs = tx & 0xFFFF; kw = (int)(tx >> 16) - xs;
+                const long long lim = ((total - 1) >> 2) * 4 - (fbase - fb3);   // offset of the last dword holding frame bytes
+#pragma unroll
+                for (int j = 0; j < ND; j++) {
+                    const long long o = (long long)(lo & ~3u) + 4 * j;
+                    p.ww[r][j] = *reinterpret_cast<const uint32_t*>(fptr + (o < lim ? o : lim));
+                }
             }
-            const unsigned lo0 = (unsigned)(ys * row_bytes + xs * 3 + fb3);        // byte offset from fptr of the bin's first byte
-            const bool wA = kw == g.kwA;                                      // a level has two bin widths: pick, don't compute
+        }
+    };
+    auto finish = [&](int pixel, const Px& p) __attribute__((always_inline)) {
+        if (pixel >= g.pix_pad) return;
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.valid) {
+            const bool wA = p.kw == g.kwA;                                      // a level has two bin widths: pick, don't compute
             const unsigned vm0 = wA ? g.vmA[0] : g.vmB[0], vm1 = wA ? g.vmA[1] : g.vmB[1], vm2 = wA ? g.vmA[2] : g.vmB[2],
                            vm3 = wA ? g.vmA[3] : g.vmB[3];
-            // the aligned 16/20-byte fetch of the LAST row may run past the end of the frame buffer only for the very
-            // last pixels of the last frame: those take per-dword clamped loads
-            const bool safe = !lastf || (lo0 & ~3u) + (unsigned)((kh - 1) * row_bytes) + 4u * ndw <= avail;
             unsigned s0 = 0, s1 = 0, s2 = 0;
-            unsigned ww[5][5], shv[5];
 #pragma unroll
-            for (int r = 0; r < 5; r++) {
-                if (r < g.khmax) {
-                    const unsigned lo = lo0 + (unsigned)((r < kh ? r : kh - 1) * row_bytes);
-                    shv[r] = lo & 3u;
-                    const char* p = fptr + (lo & ~3u);
-                    if (safe) {
-                        const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(p);
-                        ww[r][0] = v4[0]; ww[r][1] = v4[1]; ww[r][2] = v4[2]; ww[r][3] = v4[3];
-                        ww[r][4] = four ? *reinterpret_cast<const uint32_t*>(p + 16) : 0u;
-                    } else {
-                        const long long lim = ((total - 1) >> 2) * 4 - (fbase - fb3);   // offset of the last dword holding frame bytes
-#pragma unroll
-                        for (int j = 0; j < 5; j++) {
-                            const long long o = (long long)(lo & ~3u) + 4 * j;
-                            ww[r][j] = *reinterpret_cast<const uint32_t*>(fptr + (o < lim ? o : lim));
-                        }
-                    }
+            for (int r = 0; r < ROWS; r++) {
+                const bool act = r < p.kh;                                       // only the last unrolled row can be dead
+                const unsigned sh = p.shv[r];
+                const unsigned d0 = __builtin_amdgcn_alignbyte(p.ww[r][1], p.ww[r][0], sh) & (act ? vm0 : 0u);
+                const unsigned d1 = __builtin_amdgcn_alignbyte(p.ww[r][2], p.ww[r][1], sh) & (act ? vm1 : 0u);
+                const unsigned d2 = __builtin_amdgcn_alignbyte(FOUR ? p.ww[r][3] : 0u, p.ww[r][2], sh) & (act ? vm2 : 0u);
+                s0 = __builtin_amdgcn_udot4(d0, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d0, 0x00000100u, s1, false);
+                s2 = __builtin_amdgcn_udot4(d0, 0x00010000u, s2, false);
+                s0 = __builtin_amdgcn_udot4(d1, 0x00010000u, s0, false); s1 = __builtin_amdgcn_udot4(d1, 0x01000001u, s1, false);
+                s2 = __builtin_amdgcn_udot4(d1, 0x00000100u, s2, false);
+                s0 = __builtin_amdgcn_udot4(d2, 0x00000100u, s0, false); s1 = __builtin_amdgcn_udot4(d2, 0x00010000u, s1, false);
+                s2 = __builtin_amdgcn_udot4(d2, 0x01000001u, s2, false);
+                if (FOUR) {
+                    const unsigned d3 = __builtin_amdgcn_alignbyte(p.ww[r][4], p.ww[r][3], sh) & (act ? vm3 : 0u);
+                    s0 = __builtin_amdgcn_udot4(d3, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d3, 0x00000100u, s1, false);
+                    s2 = __builtin_amdgcn_udot4(d3, 0x00010000u, s2, false);
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 5; r++) {
-                if (r < g.khmax) {
-                    const bool act = r < kh;                                     // only the last unrolled row can be dead
-                    const unsigned sh = shv[r];
-                    const unsigned d0 = __builtin_amdgcn_alignbyte(ww[r][1], ww[r][0], sh) & (act ? vm0 : 0u);
-                    const unsigned d1 = __builtin_amdgcn_alignbyte(ww[r][2], ww[r][1], sh) & (act ? vm1 : 0u);
-                    const unsigned d2 = __builtin_amdgcn_alignbyte(ww[r][3], ww[r][2], sh) & (act ? vm2 : 0u);
-                    s0 = __builtin_amdgcn_udot4(d0, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d0, 0x00000100u, s1, false);
-                    s2 = __builtin_amdgcn_udot4(d0, 0x00010000u, s2, false);
-                    s0 = __builtin_amdgcn_udot4(d1, 0x00010000u, s0, false); s1 = __builtin_amdgcn_udot4(d1, 0x01000001u, s1, false);
-                    s2 = __builtin_amdgcn_udot4(d1, 0x00000100u, s2, false);
-                    s0 = __builtin_amdgcn_udot4(d2, 0x00000100u, s0, false); s1 = __builtin_amdgcn_udot4(d2, 0x00010000u, s1, false);
-                    s2 = __builtin_amdgcn_udot4(d2, 0x01000001u, s2, false);
-                    if (four) {
-                        const unsigned d3 = __builtin_amdgcn_alignbyte(ww[r][4], ww[r][3], sh) & (act ? vm3 : 0u);
-                        s0 = __builtin_amdgcn_udot4(d3, 0x01000001u, s0, false); s1 = __builtin_amdgcn_udot4(d3, 0x00000100u, s1, false);
-                        s2 = __builtin_amdgcn_udot4(d3, 0x00010000u, s2, false);
-                    }
-                }
-            }
-            o4.x = pyr_norm(s0, kh, kw, g); o4.y = pyr_norm(s1, kh, kw, g); o4.z = pyr_norm(s2, kh, kw, g);
+            o4.x = pyr_norm(s0, p.kh, p.kw, g); o4.y = pyr_norm(s1, p.kh, p.kw, g); o4.z = pyr_norm(s2, p.kh, p.kw, g);
         }
         pyr_store(pyr + ((long long)f * a.pyr_stride + g.pix0 + pixel), o4);
+    };
+    for (int pixel = q0; pixel < g.pix_pad; pixel += 2 * qstep) {
+        Px pa, pb;
+        prep(pixel, pa);
+        prep(pixel + qstep, pb);          // beyond pix_pad: invalid, nothing loaded, nothing stored
+        finish(pixel, pa);
+        finish(pixel + qstep, pb);
     }
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ frames, PyrArgs a, const uint32_t* __restrict__ tab,
                                                  float4* __restrict__ pyr) {
-    if (MODE == 0) pyr_level0(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    if (MODE == 0) pyr_level0<5, true>(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     else pyr_level<MODE>(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// mode 0, specialised on the level's row count / dword count (register budget = occupancy = loads in flight)
+template <int ROWS, bool FOUR>
+__global__ __launch_bounds__(256) void k_pyramid0(const uint8_t* __restrict__ frames, PyrArgs a, const uint32_t* __restrict__ tab,
+                                                  float4* __restrict__ pyr) {
+    pyr_level0<ROWS, FOUR>(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ---- fused PNet --------------------------------------------------------------------------------------
@@ -1098,8 +1116,12 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
             PyrArgs pa;
             pa.H = H; pa.W = W; pa.n_frames = n; pa.f0 = f0; pa.pyr_stride = a.pyr_stride; pa.g = a.lv[l];
             const int threads = pa.g.pix_pad << pa.g.gshift;
-            dim3 grid((threads + 255) / 256, nf);
-            if (pa.g.mode == 0) k_pyramid<0><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+            dim3 grid(pa.g.mode == 0 ? (threads + 511) / 512 : (threads + 255) / 256, nf);   // mode 0: two pixels per thread
+            if (pa.g.mode == 0) {
+                if (pa.g.khmax <= 3 && pa.g.nd <= 3) k_pyramid0<3, false><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+                else if (pa.g.khmax <= 4) k_pyramid0<4, true><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+                else k_pyramid0<5, true><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
+            }
             else if (pa.g.mode == 1) k_pyramid<1><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
             else k_pyramid<2><<<grid, 256, 0, s>>>(d_frames, pa, c->pyr_tab, pyr);
             TRL_LAUNCH_CHECK();
