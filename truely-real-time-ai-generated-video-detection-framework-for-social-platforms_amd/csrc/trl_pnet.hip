@@ -497,6 +497,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     for (; tile < t_end; tile = tile_nxt, cur = nxt, rot++) {
         const int f = cur.f, l = cur.l, ty = cur.ty, tx = cur.tx;
         const PLevel& g = a.lv[l];
+        const int vrows = (g.oh - ty * TS < TS) ? g.oh - ty * TS : TS;      // valid output rows of this tile
         int cursor = 0;
         if (tid == 0) cursor = atomicAdd(&a.xcd_next[xcd], 1);   // in flight during phases 0-2, published at the barrier that ends phase 2
 
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             // The 21 M-tiles split 6/5/5/5 over the waves; the 6-tile role rotates with the tile counter so that no
             // SIMD (wave i of both resident workgroups sits on SIMD i) is the long pole every time.
             const int w2 = (wave + rot) & 3;
+            const int lim2 = C2_T * (vrows + 3 < C2_T ? vrows + 3 : C2_T);   // conv2 cells conv3 reads: rows 0 .. vrows+2
             float xa[23], xb[23];
             auto read_pair2 = [&](int j) {
                 const int mtA = w2 + 8 * j, mtB = (mtA + 4 < 21) ? mtA + 4 : mtA;
@@ -611,10 +613,14 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 const int mtA = w2 + 8 * j, mtB = mtA + 4;
-                const bool hasB = mtB < 21;                    // j == 2: only wave role 0 has a second tile (M-tile 20)
+                // Tiles on the bottom edge of a level hold fewer than 16 valid output rows: conv2 cells below the rows conv3 will
+                // read are skipped (M-tile m covers cells 16m.. of the 18-wide grid).  Uniform per wave, no barrier inside.
+                const bool hasB = mtB < 21 && 16 * mtB < lim2;  // j == 2: only wave role 0 has a second tile (M-tile 20)
+                const bool hasA = 16 * mtA < lim2;
                 f32x4 accA = {bias2, bias2, bias2, bias2}, accB = accA;
                 __builtin_amdgcn_sched_barrier(0);
-                if (j < 2 || hasB) {
+                if (!hasA) {
+                } else if (hasB) {
 #pragma unroll
                     for (int s = 0; s < 23; s++) {
                         accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int ra = mtA * 16 + kq * 4 + q;
-                    if (ra < 324) RA[ra * C2_LD + l15] = prelu_t<UNIT>(accA[q], slope2);
+                    if (hasA && ra < 324) RA[ra * C2_LD + l15] = prelu_t<UNIT>(accA[q], slope2);
                     const int rb = mtB * 16 + kq * 4 + q;
                     if (hasB && rb < 324) RA[rb * C2_LD + l15] = prelu_t<UNIT>(accB[q], slope2);
                 }
@@ -650,6 +656,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 #pragma unroll 1
             for (int it = 0; it < 2; it++) {
                 const int mt = wave + 4 * it;               // 8 M-tiles of 32 rows = 2 output rows each
+                if (2 * mt >= vrows) continue;              // bottom-edge tile: these two output rows lie below the level
                 const int y = mt * 2 + (l31 >> 4), x = l31 & 15;
                 const int base = (y * C2_T + x) * C2_LD + hh;
                 f32x16 acc;
