@@ -1097,6 +1097,10 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
             t.fastdiv = g.fastdiv; t.rkh[0] = g.rkh[0]; t.rkh[1] = g.rkh[1]; t.rkw[0] = g.rkw[0]; t.rkw[1] = g.rkw[1];
         }
         if (sa.nlev == 0 || stab_words > STAB || n > 65535) return TRL_OK;
+        // Frames wider than one 4096-byte column band need several bands per row; measured at 1080p and 4K the pass then
+        // gains nothing over the per-level kernels and the PNet launch that follows runs 7-10 % slower: keep it to one band.
+        static const bool wide_env = getenv("TRL_PYR_STREAM_WIDE") && atoi(getenv("TRL_PYR_STREAM_WIDE")) != 0;
+        if (W * 3 > SBYTES && !wide_env) return TRL_OK;
         sa.H = H; sa.W = W; sa.n_frames = n; sa.pyr_stride = a.pyr_stride;
         if (W * 3 <= SBYTES) { sa.col_bands = 1; sa.cols_per_band = W; }
         else { sa.cols_per_band = SBYTES / 3 - kwm - 2; sa.col_bands = (W + sa.cols_per_band - 1) / sa.cols_per_band; }
