@@ -207,3 +207,15 @@ def test_two_contexts_on_two_threads(blob):
     for j in range(2):
         for k in ("box", "prob", "rect", "valid", "emb"):
             assert np.array_equal(got[j][k], ref[j][k]), (j, k)
+
+
+def test_analyze_video_with_batches_in_flight(blob):
+    """model.analyze_video(engines=[e0, e1]): two contexts, two streams, two threads -- same bits as the sequential call."""
+    from truely_amd.engine import Engine
+    from truely_amd.model import analyze_video
+    fr = truely_amd.synthetic.synthetic_frames(40, 360, 640, seed=51)
+    seq = analyze_video(fr, fps=30, engine=Engine(blob), batch=8)
+    par = analyze_video(fr, fps=30, engines=[Engine(blob), Engine(blob)], batch=8)
+    assert seq["score"] == par["score"] and seq["hits"] == par["hits"]
+    for k in ("box", "prob", "rect", "valid", "emb", "sims", "flags"):
+        assert torch.equal(seq[k].cpu(), par[k].cpu()), k
