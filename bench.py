@@ -1,21 +1,47 @@
-"""bench.py -- BASELINE.json metric: frames/sec (detect + embed + drift), synthetic 720p clips.
+"""bench.py -- BASELINE.json metric: frames/sec (detect + embed + drift), synthetic clips.
 
-One "step" = one pass of the hot path (server/model.py:47-66 batched) over one batch of 256
-synthetic 720p 1-face frames per GPU, inputs already resident in HBM (BASELINE.json configs[1]).
-N > 1: one process per GPU, each rank owns a contiguous time shard, one RCCL all-gather of the
-embeddings, drift on every rank (weak scaling).  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path (server/model.py:47-66 batched) over one batch of synthetic frames per
+GPU, inputs already resident in HBM.  Default workload = BASELINE.json configs[1] (256 x 720p 1-face, fp32).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  If the ranks were not started for us (no WORLD_SIZE in the environment) this
+process starts them itself -- `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>`
+as a child, BEFORE anything here touches the GPU -- and exits with the child's code.
+  --mode sharded (default): one clip, contiguous time shards per rank, ONE all-gather (RCCL) of the embedding
+                            rows per step, drift on every rank (weak scaling: per-GPU batch fixed);
+  --mode streams          : BASELINE configs[3] -- one independent clip per GPU, no data-path collective.
+  --config {1,2,4}        : which BASELINE.json configs[] entry the workload is (1 = headline, default).
+  --ingest nv12           : supplementary leg: host NV12 -> pinned H2D -> BGR on the device -> the same path.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H, W, BATCH, FPS = 720, 1280, 256, 30
+FPS = 30
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32-input MFMA peak (= f32 vector peak)
+
+# BASELINE.json configs[] -> workload.  The detector is f32 in every config (a reduced-precision detector cannot
+# keep box / NMS index parity); configs[2] runs the embedder on the bf16 matrix cores.
+CONFIGS = {
+    1: dict(H=720, W=1280, batch=256, faces=1, min_face=20, embed="f32", dtype="f32", unique=256,
+            name="BASELINE configs[1]: synthetic 720p 1-face frames, batch=256 per GPU, fp32, MTCNN detect + 80x80 crop + "
+                 "InceptionResnetV1 embed + cosine drift score"),
+    2: dict(H=1080, W=1920, batch=128, faces=-1, min_face=20, embed="bf16", dtype="f32+bf16", unique=16,
+            name="BASELINE configs[2]: synthetic 1080p multi-face (3-5 faces/frame) stream, batch=128 per GPU, f32 detector "
+                 "(bit-exact cascade) + bf16-MFMA InceptionResnetV1 embedder, largest face embedded (server/model.py:49)"),
+    4: dict(H=2160, W=3840, batch=32, faces=1, min_face=40, embed="f32", dtype="f32", unique=4,
+            name="BASELINE configs[4]: synthetic 4K frames, MTCNN pyramid 12 scales (min_face_size=40), batch=32 per GPU, "
+                 "f32 (an fp16 detector cannot keep box/NMS parity: not built, DESIGN.md section 8)"),
+}
 
 
 def pnet_macs(Hh, Ww, minsize=20, factor=0.709):
@@ -33,16 +59,30 @@ def pnet_macs(Hh, Ww, minsize=20, factor=0.709):
     return tot
 
 
-def cpu_baseline(frames_np, threads):
+def make_clip(cfg, n, seed):
+    """n seeded frames of the config's shape.  The numpy generator is slow for big frames, so `unique` frames are
+    generated and the rest are horizontal rolls of them (different bytes, same statistics)."""
+    import numpy as np
+    import truely_amd
+    u = min(n, cfg["unique"])
+    base = truely_amd.synthetic.synthetic_frames(u, cfg["H"], cfg["W"], seed=seed, faces=cfg["faces"])
+    if u == n:
+        return base
+    out = np.empty((n,) + base.shape[1:], np.uint8)
+    for i in range(n):
+        out[i] = base[i % u] if i < u else np.roll(base[i % u], 11 * (i // u), axis=1)
+    return out
+
+
+def cpu_baseline(frames_np, threads, cfg):
     """Restated reference CPU path (oracle/torch_ref.py: torch CPU fp32, ONE frame at a time exactly
     as server/model.py:42-59 drives facenet-pytorch), on a bounded sample of the same workload."""
-    import numpy as np
-    import torch
     import truely_amd
     from oracle.torch_ref import TorchRef
     from oracle.oracle import Oracle
+    H, W = cfg["H"], cfg["W"]
     sds = truely_amd.weights.synthetic_state_dicts(0)
-    ref = TorchRef(*sds, threads=threads)
+    ref = TorchRef(*sds, threads=threads, min_face_size=cfg["min_face"])
     orc = Oracle(truely_amd.weights.pack_state_dicts(*sds))
     t0 = time.time()
     done = 0
@@ -59,23 +99,54 @@ def cpu_baseline(frames_np, threads):
         done += 1
     dt = time.time() - t0
     return {"value": round(done / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{done} frames of the same synthetic 720p clip in {dt:.1f} s, torch-CPU fp32 restatement of the "
+            "sample": f"{done} frames of the same synthetic {H}p clip in {dt:.1f} s, torch-CPU fp32 restatement of the "
                       f"reference path (oracle/torch_ref.py), one frame at a time like server/model.py:42-59"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="sharded", choices=["sharded", "streams"])
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pnet-mode", type=int, default=None)
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo to rehearse the N>1 path on one GPU")
+    ap.add_argument("--prelu", default="unit", choices=["unit", "general"],
+                    help="synthetic PReLU slopes: 'unit' in [0.05,0.3] (the seeded default: max(v, s*v) fast path); 'general' "
+                         "flips some slopes outside [0,1] / negative, which real checkpoints may have (k_pnet_fused<false>)")
+    ap.add_argument("--ingest", default="resident", choices=["resident", "nv12"],
+                    help="resident (the metric: frames already in HBM) or nv12 (supplementary: pinned host NV12 -> H2D -> "
+                         "k_nv12_to_bgr -> the same path, PCIe inclusive)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo to rehearse N>1 on one GPU")
     ap.add_argument("--in-flight", type=int, default=2,
-                    help="batches in flight per GPU: each gets its own context, HIP stream and host thread, so the low-occupancy tail "
-                         "of one batch (NMS, FaceNet's 1x1-spatial layers) overlaps the wide kernels of the next; 1 = strictly sequential")
-    args = ap.parse_args()
+                    help="batches in flight per GPU: each gets its own context, HIP stream and host thread; 1 = strictly sequential")
+    ap.add_argument("--master-port", type=int, default=None)
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N fresh ranks as a child `torch.distributed.run` (never re-exec: this
+    process has not touched the GPU and never will).  torch.cuda.device_count() does not initialise HIP."""
+    import torch
+    have = torch.cuda.device_count()
+    if args.backend == "nccl" and have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} with RCCL needs {args.gpus} visible GPUs, found {have} "
+                 f"(rehearse on fewer GPUs with --backend gloo)")
+    port = args.master_port or (29500 + os.getpid() % 3000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import numpy as np
     import torch
@@ -87,8 +158,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     if args.backend != "nccl":
         local = local % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share one GPU under gloo
+    elif world > torch.cuda.device_count():
+        sys.exit(f"bench.py: {world} RCCL ranks need {world} GPUs, found {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -96,27 +171,55 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
-    n = args.batch
-    frames_np = truely_amd.synthetic.synthetic_frames(n, H, W, seed=rank, faces=1)
-    frames = torch.from_numpy(frames_np).to(dev)
+    cfg = CONFIGS[args.config]
+    H, W = cfg["H"], cfg["W"]
+    n = args.batch or cfg["batch"]
+    frames_np = make_clip(cfg, n, seed=rank)           # sharded: segment `rank` of the clip; streams: clip `rank`
     import queue
     import threading
-    blob = truely_amd.weights.synthetic_blob(0)
+    sds = truely_amd.weights.synthetic_state_dicts(0)
+    if args.prelu == "general":
+        truely_amd.weights.generalise_prelu(sds)
+    blob = truely_amd.weights.pack_state_dicts(*sds)
     F = max(1, args.in_flight)
-    engs = [Engine(blob, device=local, pnet_mode=args.pnet_mode) for _ in range(F)]   # one context + workspace per batch in flight
+    ekw = dict(device=local, pnet_mode=args.pnet_mode, min_face_size=cfg["min_face"], embed_precision=cfg["embed"])
+    if cfg["H"] > 1080:
+        ekw.update(cap_level=3072, cap_frame=3072)
+    engs = [Engine(blob, **ekw) for _ in range(F)]   # one context + workspace per batch in flight
     streams = [torch.cuda.Stream(dev) for _ in range(F)]
     eng = engs[0]
     drift_eng = Engine(blob, device=local) if F > 1 else eng      # the main thread's context (drift kernels)
-    frame_count = n * world * 4      # 30 fps clip sampled every 4th frame (model.py:40)
+    sharded = args.mode == "sharded"
+    frame_count = n * (world if sharded else 1) * 4    # 30 fps clip sampled every 4th frame (model.py:40)
+
+    if args.ingest == "nv12":
+        from truely_amd.ingest import bgr_to_nv12, Nv12Uploader
+        nv12_host = torch.from_numpy(bgr_to_nv12(frames_np)).pin_memory()   # what a decoder hands over: host NV12 planes
+        uploaders = [Nv12Uploader(engs[j], H, W, n) for j in range(F)]
+        frames = None
+    else:
+        frames = torch.from_numpy(frames_np).to(dev)
+
+    def batch_input(j):
+        """The batch as the detector consumes it.  resident: the device tensor; nv12: copy + convert on stream j."""
+        if frames is not None:
+            return frames
+        return uploaders[j].upload(nv12_host)
+
+    counts = [n] * world
 
     def finish(out):
-        """Main thread, step order on every rank: the one collective of the path, then the drift state machine."""
-        if world > 1:
-            emb, valid = allgather_embeddings(out["emb"], out["valid"])
+        """Main thread, step order on every rank: the one collective of the path (sharded mode), then the drift state machine."""
+        if world > 1 and sharded:
+            emb, valid = allgather_embeddings(out["emb"], out["valid"], counts=counts)
         else:
             emb, valid = out["emb"], out["valid"]
-        return drift_eng.drift_score(emb, valid, frame_count, FPS)
+        d = drift_eng.drift_score(emb, valid, frame_count, FPS)
+        d["emb_all"], d["valid_all"] = emb, valid
+        return d
 
     def run_steps(k):
         """k steps.  Worker j runs detect+embed of steps j, j+F, .. on its own stream; results are consumed in step order."""
@@ -124,7 +227,7 @@ def main():
         last = (None, None)
         if F == 1:
             for _ in range(k):
-                out = eng.detect_embed(frames)
+                out = eng.detect_embed(batch_input(0))
                 d = finish(out)
                 tm = eng.timings()
                 for key in acc:
@@ -138,7 +241,7 @@ def main():
                 torch.cuda.set_device(local)
                 with torch.cuda.stream(streams[j]):
                     for _i in range(j, k, F):
-                        out = engs[j].detect_embed(frames)
+                        out = engs[j].detect_embed(batch_input(j))
                         streams[j].synchronize()          # the consumer runs on another stream
                         qs[j].put((out, engs[j].timings()))
             except BaseException as e:                     # surfaced by the consumer
@@ -173,38 +276,50 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     pnet_ms, pyr_ms, pnet_kernel_ms = acc["pnet_ms"], acc["pyramid_ms"], acc["pnet_kernel_ms"]
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
+        tdev = dev if args.backend == "nccl" else torch.device("cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dt = float(tmax.item())
+        scores = [None] * world
+        dist.all_gather_object(scores, int(d["score"]))        # after the timed region: reporting only
+    else:
+        scores = [int(d["score"])]
 
     if rank == 0:
         tm = eng.timings()
-        macs = pnet_macs(H, W) * n                  # per launch set of one step on this rank
+        macs = pnet_macs(H, W, cfg["min_face"]) * n                  # per launch set of one step on this rank
         launches = max(1, tm["pnet_launches"])
-        # Duration of the dominant kernel per step.  Two clocks, both live over the timed region: HIP events recorded around the
-        # launch on its stream, and the launch's execution span on the device wall clock (first workgroup start -> last workgroup
-        # end), which is what rocprofv3 reports as the kernel's duration.  With one batch in flight they agree; with two, the event
-        # pair also counts the time the launch queues behind the other context's kernels, so the span is the kernel's time.
-        use_span = eng.cfg.pnet_mode == 0 and pnet_kernel_ms > 0
+        # Duration of the dominant kernel per step: HIP events recorded around the launch on its stream, live over the timed
+        # region.  (With two batches in flight the pair also counts time the launch spends queued behind the other context's
+        # kernels; `--in-flight 1` and the committed rocprofv3 kernel stats give the kernel's own duration.)
+        use_span = pnet_kernel_ms > 0
         pnet_s = (pnet_kernel_ms if use_span else pnet_ms) / 1e3 / args.steps
         achieved = 2.0 * macs / pnet_s / 1e12
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "round1_pnet_traffic.json")
-        if eng.cfg.pnet_mode == 0 and n == BATCH and os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "round2_pnet_traffic.json")
+        if eng.cfg.pnet_mode == 0 and args.config == 1 and n == cfg["batch"] and os.path.exists(tpath):
             # HBM bytes per launch of k_pnet_fused from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+        emb_all = d["emb_all"].cpu().numpy()
+        if world > 1 and sharded:
+            par = f"one clip frame-sharded x{world} (contiguous time shards), 1 all-gather of embedding rows per step ({args.backend})"
+        elif world > 1:
+            par = f"{world} independent clips, one per GPU (BASELINE configs[3]), no data-path collective"
+        else:
+            par = "single GPU"
         res = {
-            "metric": "frames/sec (detect+embed+drift) 720p", "value": round(n * world * args.steps / dt, 2), "unit": "frames/s",
+            "metric": f"frames/sec (detect+embed+drift) {H}p", "value": round(n * world * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic 720p 1-face frames, batch=256 per GPU, fp32, "
-                                   "MTCNN detect + 80x80 crop + InceptionResnetV1 embed + cosine drift score",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": cfg["name"] + ("" if args.mode == "sharded" or world == 1 else
+                                                  " -- as BASELINE configs[3]: 8-video concurrent ingest, one stream per GPU"),
                        "frames_per_gpu": n, "height": H, "width": W, "weights": "seeded synthetic (no checkpoints offline)",
-                       "valid_faces": int(out["valid"].sum().item()), "score": d["score"],
+                       "prelu_slopes": args.prelu, "min_face_size": cfg["min_face"], "pyramid_levels": eng.levels(H, W),
+                       "valid_faces": int(out["valid"].sum().item()), "score": d["score"], "scores": scores,
+                       "emb_crc32": zlib.crc32(emb_all.tobytes()), "mode": args.mode, "ingest": args.ingest,
                        "pnet_path": "fused" if eng.cfg.pnet_mode == 0 else "generic layers",
-                       "parallelism": f"frame-sharded x{world}, 1 all-gather of embeddings" if world > 1 else "single GPU",
-                       "batches_in_flight": F},
+                       "parallelism": par, "backend": args.backend if world > 1 else None, "batches_in_flight": F},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "kernel": "k_pnet_fused (PNet over the pyramid: 83% of the conv FLOPs at 720p)",
@@ -215,11 +330,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, len(os.sched_getaffinity(0)))
-            res["cpu_baseline"] = cpu_baseline(frames_np, threads)
+            res["cpu_baseline"] = cpu_baseline(frames_np, threads, cfg)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

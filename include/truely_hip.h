@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 3
+#define TRL_ABI_VERSION 4
 
 typedef enum {
     TRL_OK = 0,
@@ -80,6 +80,13 @@ int  trl_load_weights(trl_ctx* ctx, const void* host_blob, size_t nbytes);
 int  trl_mtcnn_detect(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
                       float* d_boxes, float* d_probs, int32_t* d_counts, void* stream);
 
+/* `mtcnn.detect(frame, landmarks=True)`: the same call returning the 5 facial landmarks O-Net predicts as well.  The
+ * reference discards them (`boxes, _ = mtcnn.detect(frame)`, server/model.py:47); facenet-pytorch computes them on every
+ * call (detect_face.py stage 3), so they are exported for callers that align faces.
+ *   d_points : f32 [n][max_faces][10]  x0..x4, y0..y4 of each face, same order as d_boxes */
+int  trl_mtcnn_detect_landmarks(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
+                                float* d_boxes, float* d_probs, float* d_points, int32_t* d_counts, void* stream);
+
 /* server/model.py:59  `facenet_model(face_tensor)`:  InceptionResnetV1(...).eval() forward.
  *   d_faces : f32 [n][h][w][3] NHWC, already scaled as model.py:58 does (to_tensor: /255)
  *   d_emb   : f32 [n][512], L2-normalised */
@@ -120,6 +127,10 @@ int  trl_ingest_nv12(trl_ctx* ctx, const uint8_t* d_nv12, int n_in, int H, int W
 int  trl_debug_stage_boxes(trl_ctx* ctx, int stage, int frame, float* h_boxes, int max_rows, int* n_out);
 /* Per-level PNet candidate / kept counts of one frame (host output, up to 32 levels each). */
 int  trl_debug_level_counts(trl_ctx* ctx, int frame, int32_t* h_cand, int32_t* h_keep, int* n_levels);
+/* Candidate records of one (frame, pyramid level) of the last call, as the PNet kernel appended them (arbitrary order):
+ * rows of 40 bytes {x1,y1,x2,y2,score,r0,r1,r2,r3 : f32; cell : i32}, cell = y*ow + x of the PNet output map.  With
+ * thr0 = 0 every cell is a candidate, so this reads the fused kernel's own probability / regression maps. */
+int  trl_debug_level_cands(trl_ctx* ctx, int frame, int level, void* h_rows, int max_rows, int* n_out);
 /* test hook: level `level` of one frame's image pyramid as the fused PNet kernel reads it; d_out holds h*w*3 floats
  * (capacity: at least (int(H*m+1))*(int(W*m+1))*3 with m = 12/min_face_size) */
 int  trl_debug_pyramid_level(trl_ctx* ctx, const uint8_t* d_frame, int H, int W, int level, float* d_out, int* h, int* w, void* stream);

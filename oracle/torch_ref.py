@@ -241,7 +241,7 @@ def _pad(boxes, w, h):
 class TorchRef:
     """MTCNN().detect + InceptionResnetV1().eval() exactly as model.py:18-19,47,59 drive them."""
 
-    def __init__(self, pnet_sd, rnet_sd, onet_sd, facenet_sd, threads: int | None = None):
+    def __init__(self, pnet_sd, rnet_sd, onet_sd, facenet_sd, threads: int | None = None, min_face_size: int = 20):
         if threads:
             torch.set_num_threads(int(threads))
         self.pnet, self.rnet, self.onet, self.facenet = PNet(), RNet(), ONet(), InceptionResnetV1()
@@ -249,7 +249,7 @@ class TorchRef:
         self.onet.load_state_dict(_sd(onet_sd)); self.facenet.load_state_dict(_sd(facenet_sd), strict=False)
         for m in (self.pnet, self.rnet, self.onet, self.facenet):
             m.eval()
-        self.minsize, self.thr, self.factor = 20, (0.6, 0.7, 0.7), 0.709
+        self.minsize, self.thr, self.factor = int(min_face_size), (0.6, 0.7, 0.7), 0.709
 
     @torch.no_grad()
     def detect(self, frame: np.ndarray, trace: dict | None = None):

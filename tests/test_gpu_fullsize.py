@@ -54,13 +54,95 @@ def test_drift_is_a_function_of_time_order_only(engine, clip720):
     assert d0["score"] == d1["score"] and torch.equal(d0["sims"], d1["sims"]) and torch.equal(d0["flags"], d1["flags"])
 
 
+_FRAME_CACHE = {}
+
+
+def _frame(H, W, faces, seed):
+    """One seeded frame (the numpy generator needs ~15 s for a 4K frame: shared between tests)."""
+    key = (H, W, faces, seed)
+    if key not in _FRAME_CACHE:
+        _FRAME_CACHE[key] = truely_amd.synthetic.synthetic_frames(1, H, W, seed=seed, faces=faces)
+    return _FRAME_CACHE[key]
+
+
+@pytest.fixture(scope="module")
+def clip1080():
+    """BASELINE configs[2] at full size: 128 x 1080p frames with 3-5 faces each (bench.make_clip: 16 generated frames,
+    the rest horizontal rolls of them -- different bytes, same statistics)."""
+    import bench
+    return bench.make_clip(bench.CONFIGS[2], 128, seed=0)
+
+
+def test_config2_full_batch_properties(engine, blob, clip1080):
+    """configs[2] as stated (1080p multi-face stream, batch=128): reproducible bit for bit, independent of the batch a
+    frame travels in, and the bf16-MFMA embedder leaves every DECISION (boxes, rects, valid mask) untouched while its
+    embeddings stay within the stated tolerance of the f32 path (cosine >= 0.99; NOT the 1e-4 bar of the default)."""
+    from truely_amd.engine import Engine
+    a = engine.detect_embed(clip1080)
+    b = engine.detect_embed(clip1080)
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        assert torch.equal(a[k], b[k]), k
+    assert int(a["valid"].sum()) >= 100
+    idx = [0, 15, 16, 77, 127]
+    sub = engine.detect_embed(clip1080[idx])
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        assert torch.equal(sub[k], a[k][idx]), k
+    counts = engine.mtcnn_detect(clip1080[:16])[2].cpu().numpy()
+    assert counts.max() >= 2                               # multi-face frames: several boxes survive the cascade
+    assert engine.levels(1080, 1920) == 12 and len(engine.level_counts(0)[0]) == 12
+    eng16 = Engine(blob, embed_precision="bf16")
+    c = eng16.detect_embed(clip1080)
+    for k in ("box", "prob", "rect", "valid"):
+        assert torch.equal(c[k], a[k]), k
+    v = a["valid"].bool()
+    cos = (c["emb"][v] * a["emb"][v]).sum(1)
+    assert float(cos.min()) >= 0.99, float(cos.min())
+    assert (c["emb"][~v] == 0).all()
+    c2 = eng16.detect_embed(clip1080)
+    assert torch.equal(c2["emb"], c["emb"])                # the bf16 path is deterministic too
+
+
+def test_config2_sampled_against_oracle(engine, oracle, clip1080):
+    engine.poison_workspaces(0xFF)
+    out = engine.detect_embed(clip1080)
+    for i in (5, 64, 120):
+        ref = oracle.detect_embed(clip1080[i:i + 1])
+        assert np.array_equal(out["box"][i].cpu().numpy(), ref["box"][0])
+        assert np.array_equal(out["rect"][i].cpu().numpy(), ref["rect"][0])
+        assert out["valid"][i].item() == ref["valid"][0]
+        assert np.array_equal(out["emb"][i].cpu().numpy(), ref["emb"][0])
+
+
+def test_config4_4k_min_face_40_twelve_levels(blob):
+    """configs[4] as stated: a 4K frame through a 12-scale pyramid (min_face_size=40), against the oracle run with the
+    same MTCNN(min_face_size=40) parameters.  (The fp16 part of configs[4] is not built: DESIGN.md section 8.)"""
+    from oracle.oracle import Oracle
+    from truely_amd.engine import Engine
+    eng = Engine(blob, min_face_size=40, cap_level=3072, cap_frame=3072)
+    orc = Oracle(blob)
+    orc.params.min_face_size = 40
+    fr = _frame(2160, 3840, 1, 32)
+    assert eng.levels(2160, 3840) == 12
+    eng.detect_embed(fr)
+    eng.poison_workspaces(0xFF)
+    out = eng.detect_embed(fr)
+    _b, _p, tr = orc.detect(fr[0], trace=True)
+    cand, keep = eng.level_counts(0)
+    assert len(cand) == 12 and cand == tr["n_cand_scale"] and keep == tr["n_keep_scale"]
+    for s in (1, 2, 3):
+        assert np.array_equal(eng.stage_boxes(s, 0), tr[f"boxes{s}"])
+    ref = orc.detect_embed(fr)
+    assert np.array_equal(out["rect"].cpu().numpy(), ref["rect"]) and np.array_equal(out["emb"].cpu().numpy(), ref["emb"])
+    assert np.array_equal(out["valid"].cpu().numpy(), ref["valid"])
+
+
 @pytest.mark.parametrize("H,W,faces,seed", [(1080, 1920, -1, 31), (2160, 3840, 1, 32)])
 def test_large_frames_against_oracle(engine, blob, oracle, H, W, faces, seed):
     """configs[2] (1080p, 3-5 faces) and configs[4] (4K, min_face_size=20 -> 14 pyramid levels), fp32 path."""
     if H > 1080:   # a 4K frame has ~3x the candidates of the default list capacity: use the largest lists
         from truely_amd.engine import Engine
         engine = Engine(blob, cap_level=3072, cap_frame=3072)
-    fr = truely_amd.synthetic.synthetic_frames(1, H, W, seed=seed, faces=faces)
+    fr = _frame(H, W, faces, seed)
     engine.detect_embed(fr)          # sizes the workspaces ...
     engine.poison_workspaces(0xFF)   # ... which are then NaN-filled, like the LDS: see test_results_do_not_depend_on_stale_memory
     out = engine.detect_embed(fr)

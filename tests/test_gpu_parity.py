@@ -40,20 +40,85 @@ def test_facenet_embed_160(engine, oracle):
     assert np.array_equal(got, ref), f"max diff {np.abs(got - ref).max()}"
 
 
+def _softmax_p1(oracle, logits):
+    """prob[:, 1] of a 2-way softmax exactly as the oracle / device compute it (orc softmax2_p1: shared fmaf-polynomial
+    exp, f32 arithmetic, one rounding per op)."""
+    out = np.empty(len(logits), np.float32)
+    for i, (a0, a1) in enumerate(np.asarray(logits, np.float32)):
+        m = max(a0, a1)
+        e0 = np.float32(oracle.expf(float(np.float32(a0 - m))))
+        e1 = np.float32(oracle.expf(float(np.float32(a1 - m))))
+        out[i] = np.float32(e1 / np.float32(e0 + e1))
+    return out
+
+
 def test_rnet_onet_bit_exact(engine, oracle):
+    """R-Net / O-Net through the layer kernels on prepared crops: regression, landmarks AND class probabilities."""
     rng = np.random.default_rng(7)
     c24 = rng.uniform(-1, 1, (37, 24, 24, 3)).astype(np.float32)
     p, r = oracle.rnet(c24)
     out = engine.rnet(_t(c24)).cpu().numpy()
     assert np.array_equal(out[:, 2:6], r)
-    # class head: compare logits through the oracle's own softmax by recomputing probabilities on device outputs
-    e = np.array([oracle.expf(float(min(a0, a1) - max(a0, a1))) for a0, a1 in out[:, :2]], np.float32)
+    assert np.array_equal(_softmax_p1(oracle, out[:, :2]), p)
     c48 = rng.uniform(-1, 1, (9, 48, 48, 3)).astype(np.float32)
     p2, r2, pts = oracle.onet(c48)
     out2 = engine.onet(_t(c48)).cpu().numpy()
     assert np.array_equal(out2[:, 2:6], r2)
     assert np.array_equal(out2[:, 6:16], pts)
-    assert e.shape == (37,)
+    assert np.array_equal(_softmax_p1(oracle, out2[:, :2]), p2)
+
+
+@pytest.mark.parametrize("H,W,seed", [(120, 160, 41), (97, 131, 21)])
+def test_fused_pnet_kernel_maps_bit_exact(blob, oracle, H, W, seed):
+    """The PRODUCTION PNet kernel's own maps (k_pnet_fused, not the generic layer path `engine.pnet_level` runs): with
+    thr0 = 0 every output cell passes `prob >= thr0`, so the candidate records are the full probability and regression
+    maps of every pyramid level.  Compared bit for bit with the oracle's PNet on the oracle's pyramid, sub-threshold
+    cells included."""
+    from truely_amd.engine import Engine
+    eng = Engine(blob, thresholds=(0.0, 0.7, 0.7), cap_level=3072, cap_frame=3072)
+    assert eng.cfg.pnet_mode == 0
+    fr = truely_amd.synthetic.synthetic_frames(2, H, W, seed=seed)
+    eng.poison_workspaces(0xFF)
+    eng.mtcnn_detect(fr)
+    levels = oracle.scales(H, W)
+    for f in range(2):
+        for l, (sc, h, w) in enumerate(levels):
+            lvl = oracle.area_resample_norm(fr[f], 0, H, 0, W, h, w)
+            p_ref, r_ref = oracle.pnet_level(lvl)
+            rows = eng.level_cands(f, l)
+            assert len(rows) == p_ref.size, (f, l, len(rows), p_ref.shape)
+            assert np.array_equal(rows["cell"], np.arange(p_ref.size))
+            assert np.array_equal(rows["score"], p_ref.reshape(-1)), f"frame {f} level {l}: prob map"
+            assert np.array_equal(rows["reg"], r_ref.reshape(-1, 4)), f"frame {f} level {l}: reg map"
+            ys, xs = np.divmod(np.arange(p_ref.size), p_ref.shape[1])
+            scf = np.float32(sc)
+            q1x = np.floor((np.float32(2) * xs.astype(np.float32) + np.float32(1)) / scf)
+            q2y = np.floor((np.float32(2) * ys.astype(np.float32) + np.float32(12)) / scf)
+            assert np.array_equal(rows["box"][:, 0], q1x) and np.array_equal(rows["box"][:, 3], q2y)
+
+
+def test_landmarks_export(engine, oracle):
+    """`mtcnn.detect(frame, landmarks=True)`: O-Net's five points, ordered like the boxes (largest area first)."""
+    from truely_amd.mtcnn import MTCNN
+    m = MTCNN(engine=engine)
+    fr = truely_amd.synthetic.synthetic_frames(3, 360, 640, seed=11)
+    seen = 0
+    for i in range(3):
+        boxes, probs, pts = m.detect(fr[i], landmarks=True)
+        _b, _p, tr = oracle.detect(fr[i], trace=True)
+        if _b is None:
+            assert boxes is None and pts is None
+            continue
+        b3, p3 = tr["boxes3"], tr["points3"]
+        area = (b3[:, 2] - b3[:, 0]) * (b3[:, 3] - b3[:, 1])
+        order = np.argsort(area, kind="stable")[::-1]            # MTCNN.detect select_largest ordering
+        assert np.array_equal(boxes, b3[order, :4]) and np.array_equal(probs, b3[order, 4])
+        exp = p3[order].reshape(-1, 2, 5).transpose(0, 2, 1)     # (k, 5, 2) = (x_j, y_j)
+        assert pts.shape == exp.shape and np.array_equal(pts, exp)
+        seen += len(order)
+    assert seen >= 1
+    bb, pp = m.detect(fr[0])                                     # the default call is unchanged
+    assert np.array_equal(bb, m.detect(fr[0], landmarks=True)[0])
 
 
 @pytest.mark.parametrize("level", [0, 2, 5])

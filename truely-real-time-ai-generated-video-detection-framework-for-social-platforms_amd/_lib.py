@@ -33,12 +33,14 @@ _SIGNATURES = {
     "trl_destroy": (C.c_int, [_vp]),
     "trl_load_weights": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "trl_mtcnn_detect": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "trl_mtcnn_detect_landmarks": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "trl_facenet_embed": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "trl_detect_embed": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trl_drift_score": (C.c_int, [_vp, _vp, _vp, _i, C.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "trl_ingest_nv12": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
     "trl_debug_stage_boxes": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "trl_debug_level_counts": (C.c_int, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
+    "trl_debug_level_cands": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "trl_debug_poison": (C.c_int, [_vp, _i]),
     "trl_debug_pyramid_level": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),
     "trl_debug_pnet_level": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),
@@ -69,7 +71,7 @@ def load(path: str | None = None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.trl_abi_version() != 3:
+    if lib.trl_abi_version() != 4:
         raise ImportError("libtruely_hip ABI mismatch")
     _lib = lib
     return lib

@@ -300,8 +300,22 @@ static void collect_timings(trl_ctx* c) {
 
 extern "C" {
 
+static int mtcnn_detect_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, float* d_points,
+                             int32_t* d_counts, void* stream);
+
 int trl_mtcnn_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, int32_t* d_counts,
                      void* stream) {
+    return mtcnn_detect_impl(c, d_frames, n, H, W, d_boxes, d_probs, nullptr, d_counts, stream);
+}
+
+int trl_mtcnn_detect_landmarks(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs,
+                               float* d_points, int32_t* d_counts, void* stream) {
+    if (!d_points) { trl_set_error("null output"); return TRL_ERR_INVALID; }
+    return mtcnn_detect_impl(c, d_frames, n, H, W, d_boxes, d_probs, d_points, d_counts, stream);
+}
+
+static int mtcnn_detect_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, float* d_points,
+                             int32_t* d_counts, void* stream) {
     TRL_CHECK(check_call(c, d_frames, n, H, W));
     if (!d_boxes || !d_probs || !d_counts) { trl_set_error("null output"); return TRL_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
@@ -314,8 +328,9 @@ int trl_mtcnn_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, f
     if (!valid) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
     TRL_HIP(hipMemsetAsync(d_boxes, 0, (size_t)n * c->cfg.max_faces * 16, s));
     TRL_HIP(hipMemsetAsync(d_probs, 0, (size_t)n * c->cfg.max_faces * 4, s));
+    if (d_points) TRL_HIP(hipMemsetAsync(d_points, 0, (size_t)n * c->cfg.max_faces * 40, s));
     TRL_HIP(hipEventRecord(c->ev_call1, s));
-    TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, d_boxes, d_probs, d_counts, box0, prob0, rect, valid, s));
+    TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, d_boxes, d_probs, d_points, d_counts, box0, prob0, rect, valid, s));
     collect_timings(c);
     return TRL_OK;
 }
@@ -337,7 +352,7 @@ int trl_detect_embed(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, f
     TRL_HIP(hipSetDevice(c->cfg.device));
     TRL_HIP(hipEventRecord(c->ev_call0, s));
     TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
-    TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, s));
+    TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, s));
     const int S = c->cfg.embed_mode == 0 ? 80 : 160;
     c->scratch.reset();
     TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * ((size_t)S * S * 110 + 400000) * 4 + (8u << 20)));
@@ -411,6 +426,23 @@ int trl_debug_level_counts(trl_ctx* c, int frame, int32_t* h_cand, int32_t* h_ke
     TRL_HIP(hipMemcpy(h_cand, c->cb.lvl_cnt + (size_t)frame * L, (size_t)L * 4, hipMemcpyDeviceToHost));
     TRL_HIP(hipMemcpy(h_keep, c->cb.lvl_keep_cnt + (size_t)frame * L, (size_t)L * 4, hipMemcpyDeviceToHost));
     *n_levels = L;
+    return TRL_OK;
+}
+
+// Candidate records (generateBoundingBox rows) one (frame, level) of the last call produced, in append order
+int trl_debug_level_cands(trl_ctx* c, int frame, int level, void* h_rows, int max_rows, int* n_out) {
+    if (!c || !c->cb.lvl_cnt || frame < 0 || frame >= c->cb.n || level < 0 || level >= c->cb.L || !h_rows || !n_out) {
+        trl_set_error("no cascade state");
+        return TRL_ERR_STATE;
+    }
+    static_assert(sizeof(Cand) == 40, "trl_debug_level_cands row layout");
+    TRL_HIP(hipDeviceSynchronize());
+    int32_t k = 0;
+    TRL_HIP(hipMemcpy(&k, c->cb.lvl_cnt + (size_t)frame * c->cb.L + level, 4, hipMemcpyDeviceToHost));
+    if (k > c->cfg.cap_level) k = c->cfg.cap_level;
+    *n_out = k;
+    const int m = k < max_rows ? k : max_rows;
+    if (m > 0) TRL_HIP(hipMemcpy(h_rows, c->cb.lvl_rec + ((size_t)frame * c->cb.L + level) * c->cfg.cap_level, (size_t)m * sizeof(Cand), hipMemcpyDeviceToHost));
     return TRL_OK;
 }
 

@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256) void k_stage3_post(int capF, float thr, const 
 
 // MTCNN.detect(select_largest=True) ordering + model.py:49-54
 __global__ __launch_bounds__(64) void k_select(int capF, int max_faces, int W, int H, const int32_t* __restrict__ n3,
-                                               const float* __restrict__ s3_box, float* __restrict__ boxes, float* __restrict__ probs,
+                                               const float* __restrict__ s3_box, const float* __restrict__ s3_pts,
+                                               float* __restrict__ boxes, float* __restrict__ probs, float* __restrict__ points,
                                                int32_t* __restrict__ counts, float* __restrict__ box0, float* __restrict__ prob0,
                                                int32_t* __restrict__ rect, uint8_t* __restrict__ valid) {
     const int f = blockIdx.x;
@@ -452,6 +453,11 @@ __global__ __launch_bounds__(64) void k_select(int capF, int max_faces, int W, i
             float* o = boxes + ((size_t)f * max_faces + rank) * 4;
             o[0] = b[5 * r]; o[1] = b[5 * r + 1]; o[2] = b[5 * r + 2]; o[3] = b[5 * r + 3];
             probs[(size_t)f * max_faces + rank] = b[5 * r + 4];
+            if (points) {   // detect(landmarks=True): points[..., j] = (x_j, y_j), stored x0..x4,y0..y4 like the stage-3 rows
+                const float* ps = s3_pts + ((size_t)f * capF + r) * 10;
+                float* po = points + ((size_t)f * max_faces + rank) * 10;
+                for (int q = 0; q < 10; q++) po[q] = ps[q];
+            }
         }
         if (rank == 0 && box0) {
             box0[4 * f] = b[5 * r]; box0[4 * f + 1] = b[5 * r + 1]; box0[4 * f + 2] = b[5 * r + 2]; box0[4 * f + 3] = b[5 * r + 3];
@@ -769,11 +775,11 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     return TRL_OK;
 }
 
-int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, int32_t* d_counts,
-                       float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, hipStream_t s) {
+int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, float* d_points,
+                       int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, hipStream_t s) {
     (void)d_frames;
     CascadeBufs& B = c->cb;
-    k_select<<<n, 64, 0, s>>>(c->cfg.cap_frame, c->cfg.max_faces, W, H, B.n3, B.s3_box, d_boxes, d_probs, d_counts, d_box0, d_prob0,
+    k_select<<<n, 64, 0, s>>>(c->cfg.cap_frame, c->cfg.max_faces, W, H, B.n3, B.s3_box, B.s3_pts, d_boxes, d_probs, d_points, d_counts, d_box0, d_prob0,
                               d_rect, d_valid);
     TRL_LAUNCH_CHECK();
     // capacity overflow is an error, not a silent truncation

@@ -76,13 +76,20 @@ class Engine:
         return frames.to(self.device, non_blocking=True).contiguous()
 
     # server/model.py:47 for a batch
-    def mtcnn_detect(self, frames):
+    def mtcnn_detect(self, frames, landmarks: bool = False):
+        """(boxes [n,max_faces,4], probs [n,max_faces], counts [n]) and, with ``landmarks=True``, points [n,max_faces,10]
+        (x0..x4, y0..y4) as the fourth element -- `mtcnn.detect(frame, landmarks=True)`."""
         fr = self._frames(frames)
         n, H, W, _ = fr.shape
         mf = self.cfg.max_faces
         boxes = torch.empty((n, mf, 4), dtype=torch.float32, device=self.device)
         probs = torch.empty((n, mf), dtype=torch.float32, device=self.device)
         counts = torch.empty((n,), dtype=torch.int32, device=self.device)
+        if landmarks:
+            points = torch.empty((n, mf, 10), dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.trl_mtcnn_detect_landmarks(self._h, _ptr(fr), n, H, W, _ptr(boxes), _ptr(probs), _ptr(points),
+                                                           _ptr(counts), self._stream()))
+            return boxes, probs, counts, points
         _lib.check(self.lib.trl_mtcnn_detect(self._h, _ptr(fr), n, H, W, _ptr(boxes), _ptr(probs), _ptr(counts), self._stream()))
         return boxes, probs, counts
 
@@ -161,6 +168,16 @@ class Engine:
         _lib.check(self.lib.trl_debug_level_counts(self._h, frame, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.byref(L)))
         return a[:L.value].tolist(), b[:L.value].tolist()
 
+    CAND_DTYPE = np.dtype([("box", np.float32, 4), ("score", np.float32), ("reg", np.float32, 4), ("cell", np.int32)])
+
+    def level_cands(self, frame: int, level: int) -> np.ndarray:
+        """Test hook: the candidate records the PNet kernel appended for (frame, level) in the last call, sorted by cell."""
+        buf = np.zeros((self.cfg.cap_level,), self.CAND_DTYPE)
+        k = C.c_int()
+        _lib.check(self.lib.trl_debug_level_cands(self._h, int(frame), int(level), buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(k)))
+        rows = buf[:min(k.value, len(buf))]
+        return rows[np.argsort(rows["cell"], kind="stable")].copy()
+
     def pnet_level(self, frame, level: int):
         fr = self._frames(frame[None] if frame.ndim == 3 else frame)
         _, H, W, _ = fr.shape
@@ -190,6 +207,15 @@ class Engine:
         out = torch.empty((n, 80, 80, 3), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.trl_debug_crop_resize(self._h, _ptr(fr), n, H, W, _ptr(rect), _ptr(valid), _ptr(out), self._stream()))
         return out
+
+    def levels(self, H: int, W: int) -> int:
+        """Number of pyramid levels MTCNN.detect builds for an (H, W) frame (detect_face.py scale loop)."""
+        m = 12.0 / self.cfg.min_face_size
+        minl, k = min(H, W) * m, 0
+        while minl >= 12:
+            k += 1
+            minl *= self.cfg.factor
+        return k
 
     def timings(self):
         t = (C.c_float * 4)()

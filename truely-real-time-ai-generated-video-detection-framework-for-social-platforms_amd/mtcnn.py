@@ -5,7 +5,8 @@
 
 ``detect`` keeps the library's return convention: for one ``(H, W, 3)`` uint8 frame it returns
 ``(boxes, probs)`` with ``boxes`` a float32 ``(k, 4)`` array sorted largest-area first
-(``select_largest=True``) or ``(None, [None])`` when no face is found; for a batch
+(``select_largest=True``) or ``(None, [None])`` when no face is found (``landmarks=True`` adds the ``(k, 5, 2)``
+O-Net landmarks as a third element, ``None`` without a face); for a batch
 ``(n, H, W, 3)`` it returns object arrays of those.  The P/R/O-Net cascade runs in
 libtruely_hip.so (see csrc/trl_cascade.hip, csrc/trl_pnet.hip)."""
 from __future__ import annotations
@@ -41,8 +42,6 @@ class MTCNN:
         return self
 
     def detect(self, img, landmarks: bool = False):
-        if landmarks:
-            raise NotImplementedError("landmarks are computed on the device but not exported yet (unused by server/model.py)")
         if isinstance(img, torch.Tensor):
             arr = img
             single = arr.dim() == 3
@@ -55,15 +54,21 @@ class MTCNN:
             single = arr.ndim == 3
             if single:
                 arr = arr[None]
-        boxes, probs, counts = self.engine.mtcnn_detect(arr)
-        boxes, probs, counts = boxes.cpu().numpy(), probs.cpu().numpy(), counts.cpu().numpy()
-        out_b, out_p = [], []
+        res = self.engine.mtcnn_detect(arr, landmarks=landmarks)
+        boxes, probs, counts = res[0].cpu().numpy(), res[1].cpu().numpy(), res[2].cpu().numpy()
+        # facenet-pytorch returns points as (k, 5, 2) = (x_j, y_j); the device rows are x0..x4, y0..y4
+        points = res[3].cpu().numpy().reshape(len(counts), -1, 2, 5).transpose(0, 1, 3, 2) if landmarks else None
+        out_b, out_p, out_l = [], [], []
         for i in range(len(counts)):
             k = int(counts[i])
             if k == 0:
-                out_b.append(None); out_p.append([None])
+                out_b.append(None); out_p.append([None]); out_l.append(None)
             else:
                 out_b.append(boxes[i, :k].copy()); out_p.append(probs[i, :k].copy())
+                if landmarks:
+                    out_l.append(points[i, :k].copy())
         if single:
-            return out_b[0], out_p[0]
+            return (out_b[0], out_p[0], out_l[0]) if landmarks else (out_b[0], out_p[0])
+        if landmarks:
+            return np.array(out_b, dtype=object), np.array(out_p, dtype=object), np.array(out_l, dtype=object)
         return np.array(out_b, dtype=object), np.array(out_p, dtype=object)

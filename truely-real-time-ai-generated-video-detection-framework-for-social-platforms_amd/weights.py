@@ -294,5 +294,19 @@ def synthetic_state_dicts(seed: int = 0, calibration: Mapping[str, float] | None
     return nets["pnet"], nets["rnet"], nets["onet"], fn
 
 
+def generalise_prelu(sds):
+    """In place: give the seeded MTCNN PReLUs slopes a trained checkpoint may have -- some above 1, some negative --
+    so the kernels' general instantiations run (k_pnet_fused<false>, PReLU-before-pool front kernels) instead of
+    the `max(v, s*v)` / pool-first shortcuts that slopes in [0, 1] allow.  bench.py --prelu general times that."""
+    pnet, rnet, onet = sds[0], sds[1], sds[2]
+    for net in (pnet, rnet, onet):
+        for key in [k for k in net if k.startswith("prelu") and k.endswith(".weight")]:
+            w = np.array(net[key], np.float32, copy=True)
+            w[::5] = np.float32(1.25)
+            w[2::7] = np.float32(-0.2)
+            net[key] = w
+    return sds
+
+
 def synthetic_blob(seed: int = 0, calibration: Mapping[str, float] | None = None) -> bytes:
     return pack_state_dicts(*synthetic_state_dicts(seed, calibration))
