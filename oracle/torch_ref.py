@@ -183,7 +183,17 @@ class InceptionResnetV1(nn.Module):
 
 # ---- detect_face restated on torch / numpy ops (RECALLED: facenet_pytorch utils/detect_face.py) ----
 
-def _nms_iou(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:
+def _margin(audit, key, values, thr):
+    """Near-threshold audit: how close did any compared value come to its decision threshold?"""
+    if audit is None or len(values) == 0:
+        return
+    d = np.abs(np.asarray(values, np.float64) - float(np.float32(thr)))
+    a = audit.setdefault(key, {"n": 0, "min_margin": float("inf"), "within_1e-5": 0, "within_1e-6": 0})
+    a["n"] += int(d.size); a["min_margin"] = min(a["min_margin"], float(d.min()))
+    a["within_1e-5"] += int((d <= 1e-5).sum()); a["within_1e-6"] += int((d <= 1e-6).sum())
+
+
+def _nms_iou(boxes: torch.Tensor, scores: torch.Tensor, thr: float, audit=None, key="iou") -> torch.Tensor:
     """torchvision.ops.nms semantics (stable descending sort, greedy, strict >)."""
     b = boxes.numpy(); s = scores.numpy()
     order = np.argsort(-s, kind="stable")
@@ -198,11 +208,12 @@ def _nms_iou(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Ten
         xx2 = np.minimum(b[i, 2], b[rest, 2]); yy2 = np.minimum(b[i, 3], b[rest, 3])
         inter = np.maximum(np.float32(0), xx2 - xx1) * np.maximum(np.float32(0), yy2 - yy1)
         ovr = inter / (area[i] + area[rest] - inter)
+        _margin(audit, key, ovr[~sup[rest]], thr)
         sup[rest[ovr > np.float32(thr)]] = True
     return torch.as_tensor(np.array(keep, dtype=np.int64))
 
 
-def _nms_min(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
+def _nms_min(boxes: np.ndarray, scores: np.ndarray, thr: float, audit=None, key="iom") -> np.ndarray:
     x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
     area = (x2 - x1 + 1) * (y2 - y1 + 1)
     I = np.argsort(scores, kind="stable")
@@ -212,6 +223,7 @@ def _nms_min(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
         w = np.maximum(np.float32(0), np.minimum(x2[i], x2[idx]) - np.maximum(x1[i], x1[idx]) + 1)
         h = np.maximum(np.float32(0), np.minimum(y2[i], y2[idx]) - np.maximum(y1[i], y1[idx]) + 1)
         o = (w * h) / np.minimum(area[i], area[idx])
+        _margin(audit, key, o, thr)
         I = idx[o <= np.float32(thr)]
     return np.array(pick, dtype=np.int64)
 
@@ -259,6 +271,9 @@ class TorchRef:
         while minl >= 12:
             scales.append(scale_i); scale_i *= self.factor; minl *= self.factor
         allb = []
+        audit = trace.setdefault("audit", {}) if trace is not None else None
+        if trace is not None:
+            trace["cand_cells"], trace["keep_cells"] = [], []
         for scale in scales:
             im = F.interpolate(imgs, size=(int(h * scale + 1), int(w * scale + 1)), mode="area")
             im = (im - 127.5) * 0.0078125
@@ -270,14 +285,20 @@ class TorchRef:
             q1 = ((2 * bb + 1) / scale).floor(); q2 = ((2 * bb + 12) / scale).floor()
             r = reg[0].permute(1, 2, 0)[mask]
             boxes = torch.cat([q1, q2, p[mask].unsqueeze(1), r], 1)
+            cells = (idx[:, 0] * p.shape[1] + idx[:, 1]).numpy()
+            _margin(audit, "pnet_prob_vs_thr0", p.numpy().reshape(-1), self.thr[0])
+            pick = _nms_iou(boxes[:, :4], boxes[:, 4], 0.5, audit, "stage1a_iou_vs_0.5") if len(boxes) else torch.zeros(0, dtype=torch.int64)
+            if trace is not None:
+                trace["cand_cells"].append(cells); trace["keep_cells"].append(cells[pick.numpy()])
             if len(boxes):
-                pick = _nms_iou(boxes[:, :4], boxes[:, 4], 0.5)
                 allb.append(boxes[pick])
         if not allb:
             return None, None
         boxes = torch.cat(allb, 0)
-        pick = _nms_iou(boxes[:, :4], boxes[:, 4], 0.7)
+        pick = _nms_iou(boxes[:, :4], boxes[:, 4], 0.7, audit, "stage1b_iou_vs_0.7")
         boxes = boxes[pick]
+        if trace is not None:
+            trace["pick1"] = pick.numpy().copy()          # positions in the concatenation of the per-scale keeps
         regw = boxes[:, 2] - boxes[:, 0]; regh = boxes[:, 3] - boxes[:, 1]
         boxes = torch.stack([boxes[:, 0] + boxes[:, 5] * regw, boxes[:, 1] + boxes[:, 6] * regh,
                              boxes[:, 2] + boxes[:, 7] * regw, boxes[:, 3] + boxes[:, 8] * regh, boxes[:, 4]]).permute(1, 0)
@@ -295,20 +316,31 @@ class TorchRef:
 
         reg, prob = self.rnet(crops(boxes, 24))
         score = prob[:, 1]; ipass = score > self.thr[1]
+        _margin(audit, "rnet_prob_vs_thr1", score.numpy(), self.thr[1])
+        if trace is not None:
+            trace["pass2"] = ipass.nonzero()[:, 0].numpy().copy()
         boxes = torch.cat((boxes[ipass, :4], score[ipass].unsqueeze(1)), 1); mv = reg[ipass]
         if len(boxes) == 0:
             return None, None
-        pick = _nms_iou(boxes[:, :4], boxes[:, 4], 0.7)
+        pick = _nms_iou(boxes[:, :4], boxes[:, 4], 0.7, audit, "stage2_iou_vs_0.7")
+        if trace is not None:
+            trace["pick2"] = trace["pass2"][pick.numpy()]     # indices into boxes1
         boxes = _rerec(_bbreg(boxes[pick], mv[pick]))
         if trace is not None:
             trace["boxes2"] = boxes.numpy().copy()
         reg, pts, prob = self.onet(crops(boxes, 48))
         score = prob[:, 1]; ipass = score > self.thr[2]
+        _margin(audit, "onet_prob_vs_thr2", score.numpy(), self.thr[2])
+        if trace is not None:
+            trace["pass3"] = ipass.nonzero()[:, 0].numpy().copy()
         boxes = torch.cat((boxes[ipass, :4], score[ipass].unsqueeze(1)), 1); mv = reg[ipass]
         if len(boxes) == 0:
             return None, None
         boxes = _bbreg(boxes, mv).numpy()
-        boxes = boxes[_nms_min(boxes[:, :4], boxes[:, 4], 0.7)]
+        pick3 = _nms_min(boxes[:, :4], boxes[:, 4], 0.7, audit, "stage3_iom_vs_0.7")
+        if trace is not None:
+            trace["pick3"] = trace["pass3"][pick3]            # indices into boxes2
+        boxes = boxes[pick3]
         if trace is not None:
             trace["boxes3"] = boxes.copy()
         order = np.argsort((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), kind="stable")[::-1]
