@@ -320,17 +320,25 @@ static int mtcnn_detect_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, 
     if (!d_boxes || !d_probs || !d_counts) { trl_set_error("null output"); return TRL_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     TRL_HIP(hipSetDevice(c->cfg.device));
-    TRL_HIP(hipEventRecord(c->ev_call0, s));
-    TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
-    // scratch for the model.py-only outputs
-    float* box0 = (float*)c->arena.alloc((size_t)n * 16); float* prob0 = (float*)c->arena.alloc((size_t)n * 4);
-    int32_t* rect = (int32_t*)c->arena.alloc((size_t)n * 16); uint8_t* valid = (uint8_t*)c->arena.alloc((size_t)n);
-    if (!valid) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
-    TRL_HIP(hipMemsetAsync(d_boxes, 0, (size_t)n * c->cfg.max_faces * 16, s));
-    TRL_HIP(hipMemsetAsync(d_probs, 0, (size_t)n * c->cfg.max_faces * 4, s));
-    if (d_points) TRL_HIP(hipMemsetAsync(d_points, 0, (size_t)n * c->cfg.max_faces * 40, s));
-    TRL_HIP(hipEventRecord(c->ev_call1, s));
-    TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, d_boxes, d_probs, d_points, d_counts, box0, prob0, rect, valid, s));
+    c->scratch_after_cascade = 0;
+    for (int attempt = 0;; attempt++) {
+        TRL_HIP(hipEventRecord(c->ev_call0, s));
+        TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
+        // scratch for the model.py-only outputs
+        float* box0 = (float*)c->arena.alloc((size_t)n * 16); float* prob0 = (float*)c->arena.alloc((size_t)n * 4);
+        int32_t* rect = (int32_t*)c->arena.alloc((size_t)n * 16); uint8_t* valid = (uint8_t*)c->arena.alloc((size_t)n);
+        if (!valid) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
+        TRL_HIP(hipMemsetAsync(d_boxes, 0, (size_t)n * c->cfg.max_faces * 16, s));
+        TRL_HIP(hipMemsetAsync(d_probs, 0, (size_t)n * c->cfg.max_faces * 4, s));
+        if (d_points) TRL_HIP(hipMemsetAsync(d_points, 0, (size_t)n * c->cfg.max_faces * 40, s));
+        TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, d_boxes, d_probs, d_points, d_counts, box0, prob0, rect, valid, s));
+        TRL_HIP(hipEventRecord(c->ev_call1, s));
+        TRL_HIP(hipStreamSynchronize(s));             // the call's one host synchronisation
+        int retry = 0;
+        TRL_CHECK(trl_cascade_check(c, n, &retry));
+        if (!retry) break;
+        if (attempt >= 3) { trl_set_error("candidate batch capacity did not converge"); return TRL_ERR_STATE; }
+    }
     collect_timings(c);
     return TRL_OK;
 }
@@ -350,19 +358,25 @@ int trl_detect_embed(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, f
     if (!d_box || !d_prob || !d_rect || !d_valid || !d_emb) { trl_set_error("null output"); return TRL_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     TRL_HIP(hipSetDevice(c->cfg.device));
-    TRL_HIP(hipEventRecord(c->ev_call0, s));
-    TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
-    TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, s));
     const int S = c->cfg.embed_mode == 0 ? 80 : 160;
-    c->scratch.reset();
-    TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * ((size_t)S * S * 110 + 400000) * 4 + (8u << 20)));
-    float* faces = (float*)c->scratch.alloc((size_t)n * S * S * 3 * 4);
-    if (!faces) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
-    if (c->cfg.embed_mode == 0) TRL_CHECK(trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, faces, s));
-    else TRL_CHECK(trl_launch_crop_area_std(d_frames, n, H, W, d_rect, d_valid, S, c->cfg.embed_mode == 2, faces, s));
-    TRL_CHECK(trl_run_facenet(c, faces, n, S, S, d_valid, d_emb, s));
-    TRL_HIP(hipEventRecord(c->ev_call1, s));
-    TRL_HIP(hipStreamSynchronize(s));
+    c->scratch_after_cascade = (size_t)n * ((size_t)S * S * 110 + 400000) * 4 + (8u << 20);
+    for (int attempt = 0;; attempt++) {
+        TRL_HIP(hipEventRecord(c->ev_call0, s));
+        TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
+        TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, s));
+        c->scratch.reset();                          // stream order: the cascade's kernels are done with it before these run
+        float* faces = (float*)c->scratch.alloc((size_t)n * S * S * 3 * 4);
+        if (!faces) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
+        if (c->cfg.embed_mode == 0) TRL_CHECK(trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, faces, s));
+        else TRL_CHECK(trl_launch_crop_area_std(d_frames, n, H, W, d_rect, d_valid, S, c->cfg.embed_mode == 2, faces, s));
+        TRL_CHECK(trl_run_facenet(c, faces, n, S, S, d_valid, d_emb, s));
+        TRL_HIP(hipEventRecord(c->ev_call1, s));
+        TRL_HIP(hipStreamSynchronize(s));             // the call's one host synchronisation
+        int retry = 0;
+        TRL_CHECK(trl_cascade_check(c, n, &retry));
+        if (!retry) break;                            // (a retry re-runs the call with larger R-/O-Net batch capacities)
+        if (attempt >= 3) { trl_set_error("candidate batch capacity did not converge"); return TRL_ERR_STATE; }
+    }
     collect_timings(c);
     return TRL_OK;
 }

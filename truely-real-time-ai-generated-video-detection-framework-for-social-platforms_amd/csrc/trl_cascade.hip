@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void k_nms_frame(int L, int cap, int capF, int
 }
 
 // exclusive scan of per-frame counts; off[n] = total.  Also the candidate -> (frame, local) map.
-__global__ __launch_bounds__(256) void k_scan_counts(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off) {
+__global__ __launch_bounds__(256) void k_scan_counts(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off, int cap_total,
+                                                     int32_t* __restrict__ flags, int slot) {
     extern __shared__ int sh[];
     for (int i = threadIdx.x; i < n; i += blockDim.x) sh[i] = cnt[i];
     __syncthreads();
@@ -305,6 +306,8 @@ __global__ __launch_bounds__(256) void k_scan_counts(const int32_t* __restrict__
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= n; i += blockDim.x) off[i] = sh[i];
+    // the batch the next stage processes was sized by an optimistic capacity: report the real total and whether it fits
+    if (threadIdx.x == 0) { flags[4 + slot] = sh[n]; if (sh[n] > cap_total) flags[2 + slot] = 1; }
 }
 __global__ void k_build_map(const int32_t* __restrict__ cnt, const int32_t* __restrict__ off, int32_t* __restrict__ map_frame,
                             int32_t* __restrict__ map_local) {
@@ -314,7 +317,7 @@ __global__ void k_build_map(const int32_t* __restrict__ cnt, const int32_t* __re
 }
 
 // ---- stage 2 tail: thr1, batched_nms(0.7), bbreg, rerec ------------------------------------------
-__global__ __launch_bounds__(256) void k_stage2_post(int capF, int W, int H, float thr, const int32_t* __restrict__ n1,
+__global__ __launch_bounds__(256) void k_stage2_post(int capF, int cap_total, int W, int H, float thr, const int32_t* __restrict__ n1,
                                                      const float* __restrict__ s1_box, const int32_t* __restrict__ off2,
                                                      const float* __restrict__ out6, int32_t* __restrict__ n2,
                                                      float* __restrict__ s2_box) {
@@ -322,7 +325,8 @@ __global__ __launch_bounds__(256) void k_stage2_post(int capF, int W, int H, flo
     Smem S(smem_raw, capF);
     const int f = blockIdx.x;
     const int cnt = n1[f];
-    if (cnt == 0) { if (threadIdx.x == 0) n2[f] = 0; return; }
+    // total past the launch capacity: out6 is incomplete, the call is re-run with a larger capacity (flag set by k_scan_counts)
+    if (cnt == 0 || off2[gridDim.x] > cap_total) { if (threadIdx.x == 0) n2[f] = 0; return; }
     const float* logits = out6 + (size_t)off2[f] * 6;
     const float* fb = s1_box + (size_t)f * capF * 5;
     const int P = next_pow2(cnt);
@@ -377,14 +381,14 @@ __global__ __launch_bounds__(256) void k_stage2_post(int capF, int W, int H, flo
 }
 
 // ---- stage 3 tail: thr2, landmarks, bbreg, nms 'Min' 0.7 --------------------------------------
-__global__ __launch_bounds__(256) void k_stage3_post(int capF, float thr, const int32_t* __restrict__ n2, const float* __restrict__ s2_box,
+__global__ __launch_bounds__(256) void k_stage3_post(int capF, int cap_total, float thr, const int32_t* __restrict__ n2, const float* __restrict__ s2_box,
                                                      const int32_t* __restrict__ off3, const float* __restrict__ out16,
                                                      int32_t* __restrict__ n3, float* __restrict__ s3_box, float* __restrict__ s3_pts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem S(smem_raw, capF);
     const int f = blockIdx.x;
     const int cnt = n2[f];
-    if (cnt == 0) { if (threadIdx.x == 0) n3[f] = 0; return; }
+    if (cnt == 0 || off3[gridDim.x] > cap_total) { if (threadIdx.x == 0) n3[f] = 0; return; }   // see k_stage2_post
     const float* logits = out16 + (size_t)off3[f] * 16;
     const float* fb = s2_box + (size_t)f * capF * 5;
     const int P = next_pow2(cnt);
@@ -563,13 +567,6 @@ int set_dyn_smem(K kernel, size_t bytes) {
     return TRL_OK;
 }
 
-int read_total(trl_ctx* c, const int32_t* d_off_n, int slot, hipStream_t s, int* out) {
-    TRL_HIP(hipMemcpyAsync(c->h_pinned + slot, d_off_n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    TRL_HIP(hipStreamSynchronize(s));
-    *out = c->h_pinned[slot];
-    return TRL_OK;
-}
-
 }  // namespace
 
 // ---- host helpers -------------------------------------------------------------------------------
@@ -675,9 +672,23 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         out = &c->pnet_ev[c->pnet_ev_used++];
         return TRL_OK;
     };
+    // capacities of the R-/O-Net candidate batches of this call, and ONE workspace big enough for every stage: it is only
+    // ever grown here, before anything is queued (growing frees the old block)
+    {
+        long long c2 = (long long)(c->t2_per_frame * n) + 64, c3 = (long long)(c->t3_per_frame * n) + 64;
+        const long long lim = (long long)n * capF;
+        c->cap_t2 = (int)(c2 < lim ? c2 : lim);
+        c->cap_t3 = (int)(c3 < lim ? c3 : lim);
+        const int ch2 = c->cap_t2 < 16384 ? c->cap_t2 : 16384, ch3 = c->cap_t3 < 4096 ? c->cap_t3 : 4096;
+        size_t need_x = (size_t)c->cap_t2 * 24 + (size_t)ch2 * (24 * 24 * 3 * 4 + 100 * 1024) + (1u << 20);
+        const size_t need3 = (size_t)c->cap_t3 * 64 + (size_t)ch3 * (48 * 48 * 3 * 4 + 640 * 1024) + (1u << 20);
+        if (need3 > need_x) need_x = need3;
+        if (c->cfg.pnet_mode == 0) { const size_t p = trl_pnet_fused_bytes(c, n, H, W) + (1u << 20); if (p > need_x) need_x = p; }
+        if (c->scratch_after_cascade > need_x) need_x = c->scratch_after_cascade;   // the embedder that follows in the same call
+        TRL_CHECK(trl_ensure(c, X, need_x));
+    }
     if (c->cfg.pnet_mode == 0) {
         // fused path: pyramid kernel + ONE persistent PNet launch over every (frame, level, tile)
-        TRL_CHECK(trl_ensure(c, X, trl_pnet_fused_bytes(c, n, H, W) + (1u << 20)));
         std::pair<hipEvent_t, hipEvent_t>*pa, *pb;
         c->pnet_ev.reserve(64);   // next_ev hands out pointers into the vector: no reallocation below
         TRL_CHECK(next_ev(pa)); TRL_CHECK(next_ev(pb));
@@ -720,57 +731,51 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     TRL_LAUNCH_CHECK();
 
     // ---- stage 2: RNet ------------------------------------------------------------------------------
-    k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n1, n, B.off2);
+    // No host round trip: the candidate total stays on the device (off2[n]).  Launches are sized by an optimistic capacity
+    // (c->cap_t2, from earlier calls) and workgroups past the real total exit at once; if the total exceeds the capacity a
+    // flag is raised and the caller re-runs the call with a larger one (trl_cascade_run).
+    const int cap2 = c->cap_t2, cap3 = c->cap_t3;
+    k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n1, n, B.off2, cap2, B.flags, 0);
     TRL_LAUNCH_CHECK();
     k_build_map<<<n, 64, 0, s>>>(B.n1, B.off2, B.map_frame, B.map_local);
     TRL_LAUNCH_CHECK();
-    int T2 = 0;
-    TRL_CHECK(read_total(c, B.off2 + n, 0, s, &T2));   // host sync: everything before is complete, scratch is free
-    X.reset();
-    float* out6 = nullptr;
-    if (T2 > 0) {
+    X.reset();   // stream order keeps the PNet workspace alive until its kernels are done: reuse needs no host sync
+    float* out6 = (float*)X.alloc((size_t)cap2 * 24);
+    {
         const int CH = 16384;
-        const int chn = T2 < CH ? T2 : CH;
-        TRL_CHECK(trl_ensure(c, X, (size_t)T2 * 24 + (size_t)chn * (24 * 24 * 3 * 4 + 100 * 1024) + (1u << 20)));
-        out6 = (float*)X.alloc((size_t)T2 * 24);
         const size_t mk = X.off;
-        for (int t0 = 0; t0 < T2; t0 += CH) {
-            const int nc = (T2 - t0 < CH) ? T2 - t0 : CH;
+        for (int t0 = 0; t0 < cap2; t0 += CH) {
+            const int nc = (cap2 - t0 < CH) ? cap2 - t0 : CH;
             X.off = mk;
             float* pool1 = (float*)X.alloc((size_t)nc * 11 * 11 * 28 * 4);
             if (!pool1 || !out6) { trl_set_error("rnet workspace"); return TRL_ERR_STATE; }
-            TRL_CHECK(trl_launch_rnet_front(c, d_frames, H, W, B.s1_box, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
-            TRL_CHECK(trl_run_rnet_tail(c, pool1, nc, out6 + (size_t)t0 * 6, s));
+            TRL_CHECK(trl_launch_rnet_front(c, d_frames, H, W, B.s1_box, B.off2 + n, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
+            TRL_CHECK(trl_run_rnet_tail(c, pool1, nc, out6 + (size_t)t0 * 6, s, B.off2 + n, t0));
         }
     }
-    k_stage2_post<<<n, 256, sm_f, s>>>(capF, W, H, c->cfg.thr1, B.n1, B.s1_box, B.off2, out6, B.n2, B.s2_box);
+    k_stage2_post<<<n, 256, sm_f, s>>>(capF, cap2, W, H, c->cfg.thr1, B.n1, B.s1_box, B.off2, out6, B.n2, B.s2_box);
     TRL_LAUNCH_CHECK();
 
     // ---- stage 3: ONet --------------------------------------------------------------------------------
-    k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n2, n, B.off3);
+    k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n2, n, B.off3, cap3, B.flags, 1);
     TRL_LAUNCH_CHECK();
     k_build_map<<<n, 64, 0, s>>>(B.n2, B.off3, B.map_frame, B.map_local);
     TRL_LAUNCH_CHECK();
-    int T3 = 0;
-    TRL_CHECK(read_total(c, B.off3 + n, 1, s, &T3));   // host sync: stage 2 finished, scratch is free again
     X.reset();
-    float* out16 = nullptr;
-    if (T3 > 0) {
+    float* out16 = (float*)X.alloc((size_t)cap3 * 64);
+    {
         const int CH = 4096;
-        const int chn = T3 < CH ? T3 : CH;
-        TRL_CHECK(trl_ensure(c, X, (size_t)T3 * 64 + (size_t)chn * (48 * 48 * 3 * 4 + 640 * 1024) + (1u << 20)));
-        out16 = (float*)X.alloc((size_t)T3 * 64);
         const size_t mk = X.off;
-        for (int t0 = 0; t0 < T3; t0 += CH) {
-            const int nc = (T3 - t0 < CH) ? T3 - t0 : CH;
+        for (int t0 = 0; t0 < cap3; t0 += CH) {
+            const int nc = (cap3 - t0 < CH) ? cap3 - t0 : CH;
             X.off = mk;
             float* pool1 = (float*)X.alloc((size_t)nc * 23 * 23 * 32 * 4);
             if (!pool1 || !out16) { trl_set_error("onet workspace"); return TRL_ERR_STATE; }
-            TRL_CHECK(trl_launch_onet_front(c, d_frames, H, W, B.s2_box, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
-            TRL_CHECK(trl_run_onet_tail(c, pool1, nc, out16 + (size_t)t0 * 16, s));
+            TRL_CHECK(trl_launch_onet_front(c, d_frames, H, W, B.s2_box, B.off3 + n, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
+            TRL_CHECK(trl_run_onet_tail(c, pool1, nc, out16 + (size_t)t0 * 16, s, B.off3 + n, t0));
         }
     }
-    k_stage3_post<<<n, 256, sm_f, s>>>(capF, c->cfg.thr2, B.n2, B.s2_box, B.off3, out16, B.n3, B.s3_box, B.s3_pts);
+    k_stage3_post<<<n, 256, sm_f, s>>>(capF, cap3, c->cfg.thr2, B.n2, B.s2_box, B.off3, out16, B.n3, B.s3_box, B.s3_pts);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
@@ -782,13 +787,30 @@ int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     k_select<<<n, 64, 0, s>>>(c->cfg.cap_frame, c->cfg.max_faces, W, H, B.n3, B.s3_box, B.s3_pts, d_boxes, d_probs, d_points, d_counts, d_box0, d_prob0,
                               d_rect, d_valid);
     TRL_LAUNCH_CHECK();
-    // capacity overflow is an error, not a silent truncation
-    TRL_HIP(hipMemcpyAsync(c->h_pinned + 4, B.flags, 16, hipMemcpyDeviceToHost, s));
-    TRL_HIP(hipStreamSynchronize(s));
-    if (c->h_pinned[4] || c->h_pinned[5]) {
+    // overflow flags + stage totals travel to pinned host memory behind the kernels; trl_cascade_check reads them after the
+    // call's ONE stream synchronisation (no host round trip inside the call)
+    TRL_HIP(hipMemcpyAsync(c->h_pinned + 4, B.flags, 32, hipMemcpyDeviceToHost, s));
+    return TRL_OK;
+}
+
+// After the stream has been synchronised.  TRL_OK; TRL_ERR_CAPACITY (a configured list capacity was exceeded: an error, never
+// a silent truncation); or *retry = 1 when the optimistic R-/O-Net batch capacity was too small -- the capacities have been
+// raised and the caller runs the call again (results of the first attempt are incomplete, not wrong-but-plausible).
+int trl_cascade_check(trl_ctx* c, int n, int* retry) {
+    const int32_t* f = c->h_pinned + 4;   // [0] cap_level, [1] cap_frame, [2] T2 overflow, [3] T3 overflow, [4] T2, [5] T3
+    *retry = 0;
+    if (f[0] || f[1]) {
         trl_set_error("candidate list overflow (cap_level=%d%s, cap_frame=%d%s): raise the capacities in trl_config",
-                      c->cfg.cap_level, c->h_pinned[4] ? " EXCEEDED" : "", c->cfg.cap_frame, c->h_pinned[5] ? " EXCEEDED" : "");
+                      c->cfg.cap_level, f[0] ? " EXCEEDED" : "", c->cfg.cap_frame, f[1] ? " EXCEEDED" : "");
         return TRL_ERR_CAPACITY;
+    }
+    // keep ~25 % headroom over the largest batch seen, so a drifting clip rarely needs a second attempt
+    const float want2 = 1.25f * (float)f[4] / (float)n + 1.f, want3 = 1.25f * (float)f[5] / (float)n + 1.f;
+    if (f[2]) { c->t2_per_frame = want2; *retry = 1; }       // stage 3 ran on an incomplete stage 2: its total is meaningless
+    else if (f[3]) { c->t3_per_frame = want3; *retry = 1; }
+    if (!*retry) {
+        if (want2 > c->t2_per_frame) c->t2_per_frame = want2;
+        if (want3 > c->t3_per_frame) c->t3_per_frame = want3;
     }
     return TRL_OK;
 }

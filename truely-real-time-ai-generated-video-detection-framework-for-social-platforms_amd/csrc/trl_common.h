@@ -60,6 +60,10 @@ struct ConvArgs {
     float* y; int ldy, yoff;
     int KH, KW, sh, sw, ph, pw, Cout, OH, OW, act;
     int M;                        // N*OH*OW
+    // Device-sized batches (R-/O-Net candidate lists): when m_dev is set the launch covers a CAPACITY of N items and only the
+    // first clamp(*m_dev - m_base, 0, N) exist; workgroups whose rows all lie past them exit at once (rows past the count
+    // inside a live workgroup compute on in-bounds scratch and are never read).  No host round trip to size the grid.
+    const int32_t* m_dev = nullptr; int m_base = 0; int m_per = 1;
     int lowp = 0;                 // 1: x, y, res are bf16 and the weights come from wt (conv_bf16, FaceNet only)
     const uint16_t* wt = nullptr; int ldwt = 0;
 };
@@ -77,10 +81,20 @@ struct Arena {
     }
 };
 
+#ifdef __HIPCC__
+__device__ __forceinline__ int trl_live_rows(const ConvArgs& a) {   // rows of the GEMM that exist (uniform: scalar loads)
+    if (!a.m_dev) return a.M;
+    int t = *a.m_dev - a.m_base;
+    t = t < 0 ? 0 : (t > a.N ? a.N : t);
+    return t * a.m_per;
+}
+#endif
+
 // ---- kernels (launch wrappers) ----------------------------------------------------------------
 int trl_launch_conv(const ConvArgs& a, hipStream_t s);
 int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st,
-                       int ceil_mode, float* y, int ldy, int yoff, int OH, int OW, hipStream_t s);
+                       int ceil_mode, float* y, int ldy, int yoff, int OH, int OW, hipStream_t s,
+                       const int32_t* n_dev = nullptr, int n_base = 0);
 int trl_launch_gap(const float* x, int N, int HW, int C, float* y, hipStream_t s);
 // reduced-precision embedder (trl_bf16.hip)
 int trl_launch_conv_bf16(const ConvArgs& a, hipStream_t s);

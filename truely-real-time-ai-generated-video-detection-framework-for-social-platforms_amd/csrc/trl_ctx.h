@@ -53,6 +53,11 @@ struct trl_ctx {
     unsigned long long* pnet_clk = nullptr;   // device: first-start / last-end wall clock of the fused PNet launch
     float pnet_kernel_ms = 0.f;      // its span in ms (collect_timings)
     int dbg_poison = -1;             // >= 0 after trl_debug_poison: byte written into every newly allocated workspace
+    // Optimistic capacities of the R-Net / O-Net candidate batches (candidates per frame): launches are sized by them and
+    // exit early on the device; a call that overflows one is re-run with a larger value (trl_cascade.hip)
+    float t2_per_frame = 160.f, t3_per_frame = 48.f;
+    int cap_t2 = 0, cap_t3 = 0;      // capacities of the call in progress
+    size_t scratch_after_cascade = 0;   // scratch bytes the rest of the call needs (crops + FaceNet): sized with the cascade's
     int rnet_front_mode = -1, onet_front_mode = -1;   // conv1 PReLU slope class (trl_front.hip), -1 = not yet classified
     uint32_t* pyr_tab = nullptr;     // pyramid bin-edge tables for the last (H, W)
     int pyr_tab_H = 0, pyr_tab_W = 0;
@@ -66,10 +71,11 @@ const DevV* trl_v(trl_ctx* c, const std::string& name);
 int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const uint8_t* d_valid, float* d_emb, hipStream_t s);
 int trl_run_rnet(trl_ctx* c, const float* d_crops, int n, float* d_out6, hipStream_t s);
 int trl_run_onet(trl_ctx* c, const float* d_crops, int n, float* d_out16, hipStream_t s);
-int trl_run_rnet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out6, hipStream_t s);
-int trl_run_onet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out16, hipStream_t s);
-int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, int t0, int nc, float* d_pool, hipStream_t s);
-int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, int t0, int nc, float* d_pool, hipStream_t s);
+// n = CAPACITY of the launch; the candidates that exist are clamp(*n_dev - n_base, 0, n) (device-sized, no host sync)
+int trl_run_rnet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out6, hipStream_t s, const int32_t* n_dev = nullptr, int n_base = 0);
+int trl_run_onet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out16, hipStream_t s, const int32_t* n_dev = nullptr, int n_base = 0);
+int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, const int32_t* d_total, int t0, int nc, float* d_pool, hipStream_t s);
+int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, const int32_t* d_total, int t0, int nc, float* d_pool, hipStream_t s);
 // PNet on one materialised level for nf frames: heads [nf][oh][ow][6]
 int trl_run_pnet_generic(trl_ctx* c, const float* d_level, int nf, int h, int w, float* d_heads, hipStream_t s);
 size_t trl_pnet_generic_bytes(int nf, int h, int w);
@@ -78,6 +84,7 @@ size_t trl_pnet_generic_bytes(int nf, int h, int w);
 int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipStream_t s);
 int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, float* d_points,
                        int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, hipStream_t s);
+int trl_cascade_check(trl_ctx* c, int n, int* retry);   // after the call's stream synchronisation
 int trl_launch_crop_resize80(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid,
                              float* d_faces, hipStream_t s);
 int trl_launch_crop_area_std(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid, int S,

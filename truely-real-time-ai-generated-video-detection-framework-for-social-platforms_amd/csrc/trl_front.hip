@@ -35,7 +35,8 @@ __device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF
 template <int S, int C1, int R, int MODE>
 __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__ frames, int nframes, int H, int W, int capF,
                                                      const float* __restrict__ boxes, const int32_t* __restrict__ map_frame,
-                                                     const int32_t* __restrict__ map_local, int t0, const float* __restrict__ w1,
+                                                     const int32_t* __restrict__ map_local, const int32_t* __restrict__ d_total, int t0,
+                                                     const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ s1,
                                                      float* __restrict__ out, int dbg_skip) {
     constexpr int CW = S - 2;                        // conv1 output side
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int t = t0 + blockIdx.x;
+    if (t >= *d_total) return;          // the launch is sized by a capacity; candidates past the device-side total do not exist
 
     // ---- crop + area resample + normalise -> in_s [S][S][3] ----------------------------------------------
     // Each WAVE owns output rows oy = wave, wave+4, ...: (1) column sums of the bin's source rows, lanes along
@@ -361,30 +363,30 @@ int slope_mode(const DevV* sl, int n) {
 static int front_dbg() { static const int v = getenv("TRL_FRONT_SKIP") ? atoi(getenv("TRL_FRONT_SKIP")) : 0; return v; }
 
 // R-Net front: pooled [nc][11][11][28]
-int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, int t0, int nc, float* d_pool,
-                          hipStream_t s) {
+int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, const int32_t* d_total, int t0, int nc,
+                          float* d_pool, hipStream_t s) {
     if (nc <= 0) return TRL_OK;
     const DevW* w = trl_w(c, "rnet.conv1.w");
     const DevV *b = trl_v(c, "rnet.conv1.b"), *sl = trl_v(c, "rnet.prelu1");
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("rnet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->rnet_front_mode < 0) c->rnet_front_mode = slope_mode(sl, 28);
 #define TRL_RF(MODE) k_mtcnn_front<24, 28, 4, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
-                                                                       c->cb.map_local, t0, w->p, b->p, sl->p, d_pool, front_dbg() & 3)
+                                                                       c->cb.map_local, d_total, t0, w->p, b->p, sl->p, d_pool, front_dbg() & 3)
     if (c->rnet_front_mode == 2) TRL_RF(2); else if (c->rnet_front_mode == 1) TRL_RF(1); else TRL_RF(0);
 #undef TRL_RF
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
 // O-Net front: pooled [nc][23][23][32]
-int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, int t0, int nc, float* d_pool,
-                          hipStream_t s) {
+int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, const int32_t* d_total, int t0, int nc,
+                          float* d_pool, hipStream_t s) {
     if (nc <= 0) return TRL_OK;
     const DevW* w = trl_w(c, "onet.conv1.w");
     const DevV *b = trl_v(c, "onet.conv1.b"), *sl = trl_v(c, "onet.prelu1");
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("onet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->onet_front_mode < 0) c->onet_front_mode = slope_mode(sl, 32);
 #define TRL_OF(MODE) k_mtcnn_front<48, 32, 3, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
-                                                                       c->cb.map_local, t0, w->p, b->p, sl->p, d_pool, (front_dbg() >> 2) & 3)
+                                                                       c->cb.map_local, d_total, t0, w->p, b->p, sl->p, d_pool, (front_dbg() >> 2) & 3)
     if (c->onet_front_mode == 2) TRL_OF(2); else if (c->onet_front_mode == 1) TRL_OF(1); else TRL_OF(0);
 #undef TRL_OF
     TRL_LAUNCH_CHECK();

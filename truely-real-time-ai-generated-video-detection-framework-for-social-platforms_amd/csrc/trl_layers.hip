@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void conv_igemm(ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= trl_live_rows(a)) return;     // device-sized batch: nothing of this tile exists (block-uniform)
 
     // ---- per-thread A row ------------------------------------------------------------------
     const int row = tid % BM;
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void conv_splitk4(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= trl_live_rows(a)) return;     // device-sized batch: nothing of this tile exists (block-uniform)
     const int segK = a.K >> 2, ks = wave * segK, ke = ks + segK;
 
     const int m = m0 + r;
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256) void conv_splitk4_tap(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= trl_live_rows(a)) return;     // device-sized batch: nothing of this tile exists (block-uniform)
     const int segK = a.K >> 2, ks = wave * segK;
 
     const int m = m0 + r;
@@ -449,6 +452,7 @@ __global__ __launch_bounds__(256) void conv_tap(ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= trl_live_rows(a)) return;     // device-sized batch: nothing of this tile exists (block-uniform)
 
     // ---- per-thread A row: element offset of (image, iy0, ix0, channel 4*g0) from a.x ---------------------
     const int row = tid % BM, g0 = tid / BM;
@@ -592,6 +596,7 @@ __global__ __launch_bounds__(256) void conv_tap48(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * BM;
+    if (m0 >= trl_live_rows(a)) return;     // device-sized batch: nothing of this tile exists (block-uniform)
 
     const int row = tid % BM, g0 = tid / BM;
     const int m = m0 + row;
@@ -737,8 +742,13 @@ int launch_cfg(const ConvArgs& a, bool vec, hipStream_t s) {
 // ---- max pool -------------------------------------------------------------------------------
 template <int V>   // V channels per thread (4 when every stride / offset is a multiple of 4 floats)
 __global__ void maxpool_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx, int xoff,
-                               int k, int st, float* __restrict__ y, int ldy, int yoff, int OH, int OW) {
+                               int k, int st, float* __restrict__ y, int ldy, int yoff, int OH, int OW,
+                               const int32_t* __restrict__ n_dev, int n_base) {
     const int CV = C / V;
+    if (n_dev) {   // device-sized batch: the first clamp(*n_dev - n_base, 0, N) items exist
+        int t = *n_dev - n_base;
+        N = t < 0 ? 0 : (t > N ? N : t);
+    }
     const size_t total = (size_t)N * OH * OW * CV;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % CV) * V;
@@ -915,7 +925,7 @@ int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
 }
 
 int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st, int ceil_mode,
-                       float* y, int ldy, int yoff, int OH, int OW, hipStream_t s) {
+                       float* y, int ldy, int yoff, int OH, int OW, hipStream_t s, const int32_t* n_dev, int n_base) {
     (void)ceil_mode;
     const bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (xoff % 4 == 0) && (ldy % 4 == 0) && (yoff % 4 == 0) &&
                     (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0);
@@ -923,8 +933,8 @@ int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int 
     if (total == 0) return TRL_OK;
     size_t blocks = (total + 255) / 256;
     if (blocks > 32768) blocks = 32768;
-    if (v4) maxpool_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW);
-    else maxpool_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW);
+    if (v4) maxpool_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW, n_dev, n_base);
+    else maxpool_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW, n_dev, n_base);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }

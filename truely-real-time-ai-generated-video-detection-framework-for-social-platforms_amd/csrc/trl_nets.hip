@@ -12,6 +12,8 @@ struct Runner {
     trl_ctx* c;
     hipStream_t s;
     int err = TRL_OK;
+    const int32_t* m_dev = nullptr;   // device-sized batch (candidate lists): item count lives on the device, see ConvArgs
+    int m_base = 0;
 
     Act alloc(int n, int h, int w, int ch, bool bf = false) {
         Act a;
@@ -52,6 +54,7 @@ struct Runner {
         a.KH = kh; a.KW = kw; a.sh = sh; a.sw = sw; a.ph = ph; a.pw = pw;
         a.Cout = w->Cout; a.OH = OH; a.OW = OW; a.act = act;
         a.M = x.n * OH * OW;
+        a.m_dev = m_dev; a.m_base = m_base; a.m_per = OH * OW;
         if (x.bf) {   // reduced-precision embedder: bf16 in / out / residual, transposed bf16 weights
             if (!w->pt || y.bf != true || (res && !res->bf) || act == TRL_ACT_PRELU) {
                 trl_set_error("bf16 conv without bf16 weights / destination");
@@ -93,7 +96,7 @@ struct Runner {
             if (e != TRL_OK) err = e;
             return y;
         }
-        int e = trl_launch_maxpool(x.p, x.n, x.h, x.w, x.c, x.ld, x.coff, k, st, ceil_mode, y.p, y.ld, y.coff, OH, OW, s);
+        int e = trl_launch_maxpool(x.p, x.n, x.h, x.w, x.c, x.ld, x.coff, k, st, ceil_mode, y.p, y.ld, y.coff, OH, OW, s, m_dev, m_base);
         if (e != TRL_OK) err = e;
         return y;
     }
@@ -230,9 +233,10 @@ int trl_run_onet(trl_ctx* c, const float* d_crops, int n, float* d_out16, hipStr
 }
 
 // R-Net from the fused front end's pooled map [n][11][11][28]
-int trl_run_rnet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out6, hipStream_t s) {
+int trl_run_rnet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out6, hipStream_t s, const int32_t* n_dev, int n_base) {
     if (n <= 0) return TRL_OK;
     Runner R{c, s};
+    R.m_dev = n_dev; R.m_base = n_base;
     Act x; x.p = const_cast<float*>(d_pool1); x.n = n; x.h = 11; x.w = 11; x.c = 28; x.ld = 28; x.coff = 0;
     x = R.mconv(x, "rnet", "conv2", "prelu2", 3);
     x = R.pool(x, 3, 2, 1);
@@ -244,9 +248,10 @@ int trl_run_rnet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out6, hi
     return R.err;
 }
 // O-Net from the fused front end's pooled map [n][23][23][32]
-int trl_run_onet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out16, hipStream_t s) {
+int trl_run_onet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out16, hipStream_t s, const int32_t* n_dev, int n_base) {
     if (n <= 0) return TRL_OK;
     Runner R{c, s};
+    R.m_dev = n_dev; R.m_base = n_base;
     Act x; x.p = const_cast<float*>(d_pool1); x.n = n; x.h = 23; x.w = 23; x.c = 32; x.ld = 32; x.coff = 0;
     x = R.mconv(x, "onet", "conv2", "prelu2", 3);
     x = R.pool(x, 3, 2, 1);
