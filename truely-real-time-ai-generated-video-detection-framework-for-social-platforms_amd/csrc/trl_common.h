@@ -64,6 +64,7 @@ struct ConvArgs {
     // first clamp(*m_dev - m_base, 0, N) exist; workgroups whose rows all lie past them exit at once (rows past the count
     // inside a live workgroup compute on in-bounds scratch and are never read).  No host round trip to size the grid.
     const int32_t* m_dev = nullptr; int m_base = 0; int m_per = 1;
+    int ysplit = 1 << 30, yskip = 0;   // output column n >= ysplit is stored yskip channels further right (trl_fnconv.hip only)
     int lowp = 0;                 // 1: x, y, res are bf16 and the weights come from wt (conv_bf16, FaceNet only)
     const uint16_t* wt = nullptr; int ldwt = 0;
 };
@@ -92,6 +93,9 @@ __device__ __forceinline__ int trl_live_rows(const ConvArgs& a) {   // rows of t
 
 // ---- kernels (launch wrappers) ----------------------------------------------------------------
 int trl_launch_conv(const ConvArgs& a, hipStream_t s);
+bool trl_fn_split4_rule(const ConvArgs& a);                                // the oracle's four-chain rule applies to the layer
+bool trl_fn_eligible(const ConvArgs& a);                                   // trl_fnconv.hip: small-map conv family
+int trl_launch_fn_group(const ConvArgs* convs, int nz, hipStream_t s);     // 1..3 independent convs in one launch
 int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st,
                        int ceil_mode, float* y, int ldy, int yoff, int OH, int OW, hipStream_t s,
                        const int32_t* n_dev = nullptr, int n_base = 0);

@@ -884,6 +884,7 @@ __global__ __launch_bounds__(256) void drift_scan_kernel(const float* __restrict
 
 int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
     if (a.M <= 0) return TRL_OK;
+    if (trl_fn_eligible(a)) return trl_launch_fn_group(&a, 1, s);   // small maps (FaceNet's 7x7 / 3x3 / 1x1 stages): trl_fnconv.hip
     const bool vec = (a.Cin % 4 == 0) && (a.ldx % 4 == 0) && (a.xoff % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
     // The oracle's four-chain rule for tiny maps with long reductions (oracle/trl_oracle.c conv2d)
     if (a.OH * a.OW <= 9 && a.K >= 512 && (a.K & 15) == 0) {

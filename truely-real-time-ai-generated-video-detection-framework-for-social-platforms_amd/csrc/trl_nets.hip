@@ -5,6 +5,7 @@
 // Activations are NHWC f32 in the context arena; a concat is a channel slice of a wider
 // buffer (Act.coff / Act.ld), so torch.cat costs nothing.
 #include "trl_ctx.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +33,25 @@ struct Runner {
         return a;
     }
 
+    // Deferred launches: convs queued between begin_group() and end_group() are independent of each other and go out as ONE
+    // launch when the small-map family takes them all (trl_launch_fn_group), else one by one in order.
+    std::vector<ConvArgs> pending;
+    bool grouping = false;
+    int ysplit = 1 << 30, yskip = 0;   // destination scatter of the next conv: output column n >= ysplit lands yskip channels further
+    void begin_group() { grouping = true; pending.clear(); }
+    void end_group() {
+        grouping = false;
+        if (pending.empty() || err != TRL_OK) { pending.clear(); return; }
+        bool all = pending.size() <= 3;
+        for (auto& a : pending) all = all && trl_fn_eligible(a);
+        if (all) for (auto& a : pending) all = all && (trl_fn_split4_rule(a) == trl_fn_split4_rule(pending[0]));
+        int st = TRL_OK;
+        if (all) st = trl_launch_fn_group(pending.data(), (int)pending.size(), s);
+        else for (auto& a : pending) { st = trl_launch_conv(a, s); if (st != TRL_OK) break; }
+        if (st != TRL_OK) err = st;
+        pending.clear();
+    }
+
     // generic conv launcher; `into` selects a pre-allocated (concat) destination view
     Act conv(const Act& x, const DevW* w, const DevV* bias, const DevV* scale, const DevV* shift, const DevV* slope,
              int kh, int kw, int sh, int sw, int ph, int pw, int act, const Act* into, const Act* res, float res_scale) {
@@ -55,6 +75,8 @@ struct Runner {
         a.Cout = w->Cout; a.OH = OH; a.OW = OW; a.act = act;
         a.M = x.n * OH * OW;
         a.m_dev = m_dev; a.m_base = m_base; a.m_per = OH * OW;
+        a.ysplit = ysplit; a.yskip = yskip;
+        if (yskip && !trl_fn_eligible(a)) { trl_set_error("scattered destination needs the small-map conv family"); err = TRL_ERR_STATE; return y; }
         if (x.bf) {   // reduced-precision embedder: bf16 in / out / residual, transposed bf16 weights
             if (!w->pt || y.bf != true || (res && !res->bf) || act == TRL_ACT_PRELU) {
                 trl_set_error("bf16 conv without bf16 weights / destination");
@@ -67,6 +89,7 @@ struct Runner {
             if (st != TRL_OK) err = st;
             return y;
         }
+        if (grouping) { pending.push_back(a); return y; }
         int st = trl_launch_conv(a, s);
         if (st != TRL_OK) err = st;
         return y;
@@ -113,6 +136,24 @@ Act block35(Runner& R, const Act& x, const std::string& p) {
     R.bconv(b2, p + ".branch2.2", 3, 3, 1, 1, 1, 1, &s2);             // final branch2 at 64:96
     return R.resid(cat, x, p + ".conv2d", 0.17f, true);
 }
+// The same block in 4 launches for the small-map conv family (f32, M <= 16384): the fused 1x1 scatters its columns into a
+// 128-wide buffer W = [branch0 | (free) | branch2.0 | branch1.0], so the two independent 3x3s can share ONE launch without a
+// hazard -- branch1.1 reads W[96:128] and writes the free slot W[32:64] (nobody reads it), branch2.1 reads W[64:96] into a
+// temporary -- then branch2.2 writes W[64:96] and the up-projection reads W[0:96] = [branch0 | branch1 | branch2].
+Act block35_grouped(Runner& R, const Act& x, const std::string& p) {
+    Act W = R.alloc(x.n, x.h, x.w, 128, false);
+    Act w96 = Runner::slice(W, 0, 96);
+    Act f1 = Runner::slice(W, 32, 32), f2 = Runner::slice(W, 64, 32), f3 = Runner::slice(W, 96, 32);
+    R.ysplit = 32; R.yskip = 32;                                      // columns >= 32 land 32 channels further right
+    R.bconv(x, p + ".fused", 1, 1, 1, 1, 0, 0, &w96);                 // [branch0 | - | branch2.0 | branch1.0]
+    R.ysplit = 1 << 30; R.yskip = 0;
+    R.begin_group();
+    Act b2 = R.bconv(f2, p + ".branch2.1", 3, 3, 1, 1, 1, 1);         // W[64:96] -> temporary
+    R.bconv(f3, p + ".branch1.1", 3, 3, 1, 1, 1, 1, &f1);             // W[96:128] -> W[32:64]
+    R.end_group();
+    R.bconv(b2, p + ".branch2.2", 3, 3, 1, 1, 1, 1, &f2);             // -> W[64:96] (branch2.0 is dead)
+    return R.resid(w96, x, p + ".conv2d", 0.17f, true);
+}
 Act block17(Runner& R, const Act& x, const std::string& p) {
     Act cat = R.alloc(x.n, x.h, x.w, 256, x.bf);
     Act s1 = Runner::slice(cat, 128, 128);
@@ -153,7 +194,8 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
     x = R.bconv(x, f + "conv2d_4b", 3, 3, 2, 2, 0, 0);
     if (R.err != TRL_OK) return R.err;
     if (x.h < 3 || x.w < 3) { trl_set_error("face crop %dx%d too small for InceptionResnetV1", h, w); return TRL_ERR_INVALID; }
-    for (int i = 0; i < 5; i++) x = block35(R, x, f + "repeat_1." + std::to_string(i));
+    const bool small_f32 = !x.bf && (long long)x.n * x.h * x.w <= 16384 && getenv("TRL_NO_FNCONV") == nullptr;
+    for (int i = 0; i < 5; i++) x = small_f32 ? block35_grouped(R, x, f + "repeat_1." + std::to_string(i)) : block35(R, x, f + "repeat_1." + std::to_string(i));
     {   // Mixed_6a
         const int OH = (x.h - 3) / 2 + 1, OW = (x.w - 3) / 2 + 1;
         Act cat = R.alloc(n, OH, OW, 896, x.bf);
@@ -175,9 +217,11 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
             s3 = Runner::slice(cat, 896, 896);
         Act t = R.bconv(x, f + "mixed_7a.fused", 1, 1, 1, 1, 0, 0);   // [branch0.0 | branch1.0 | branch2.0]
         Act t0 = Runner::slice(t, 0, 256), t1 = Runner::slice(t, 256, 256), t2 = Runner::slice(t, 512, 256);
+        R.begin_group();                                              // three independent convs over slices of t: one launch
         R.bconv(t0, f + "mixed_7a.branch0.1", 3, 3, 2, 2, 0, 0, &s0);
         R.bconv(t1, f + "mixed_7a.branch1.1", 3, 3, 2, 2, 0, 0, &s1);
         Act a2 = R.bconv(t2, f + "mixed_7a.branch2.1", 3, 3, 1, 1, 1, 1);
+        R.end_group();
         R.bconv(a2, f + "mixed_7a.branch2.2", 3, 3, 2, 2, 0, 0, &s2);
         R.pool(x, 3, 2, 0, &s3);
         x = cat;
@@ -186,10 +230,15 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
     x = block8(R, x, f + "block8", 1.0f, false);
     if (R.err != TRL_OK) return R.err;
     // avgpool_1a -> last_linear (no bias) -> last_bn (folded) -> F.normalize
-    Act g = R.alloc(n, 1, 1, x.c);
-    if (R.err != TRL_OK) return R.err;
-    if (x.bf) TRL_CHECK(trl_launch_gap_bf16(reinterpret_cast<const uint16_t*>(x.p), n, x.h * x.w, x.c, g.p, s));
-    else TRL_CHECK(trl_launch_gap(x.p, n, x.h * x.w, x.c, g.p, s));
+    Act g;
+    if (!x.bf && x.h * x.w == 1 && x.coff == 0 && x.ld == x.c) {
+        g = x;                                   // a 1x1 map IS its average (sum of one element / 1.0f, exact): no kernel
+    } else {
+        g = R.alloc(n, 1, 1, x.c);
+        if (R.err != TRL_OK) return R.err;
+        if (x.bf) TRL_CHECK(trl_launch_gap_bf16(reinterpret_cast<const uint16_t*>(x.p), n, x.h * x.w, x.c, g.p, s));
+        else TRL_CHECK(trl_launch_gap(x.p, n, x.h * x.w, x.c, g.p, s));
+    }
     Act e = R.conv(g, trl_w(c, f + "last_linear.w"), nullptr, trl_v(c, f + "last_bn.scale"), trl_v(c, f + "last_bn.shift"),
                    nullptr, 1, 1, 1, 1, 0, 0, TRL_ACT_NONE, nullptr, nullptr, 0.f);
     if (R.err != TRL_OK) return R.err;
