@@ -219,3 +219,76 @@ def test_analyze_video_with_batches_in_flight(blob):
     assert seq["score"] == par["score"] and seq["hits"] == par["hits"]
     for k in ("box", "prob", "rect", "valid", "emb", "sims", "flags"):
         assert torch.equal(seq[k].cpu(), par[k].cpu()), k
+
+
+def test_run_streams_in_bounded_windows(engine, oracle, tmp_path, monkeypatch):
+    """model.run holds one window of frames, not the clip: with a 2-sampled-frame window a 40-frame clip takes 5 flushes and the
+    score, the annotations' inputs and the output stream equal the single-batch result."""
+    from truely_amd import engine as eng_mod, model, video_io
+    monkeypatch.setattr(eng_mod, "_default", engine)
+    H, W, fps = 180, 320, 30
+    fr = truely_amd.synthetic.synthetic_frames(40, H, W, seed=3)
+    src = str(tmp_path / "in.trlv")
+    video_io.write_raw(src, fr, fps)
+    monkeypatch.setenv("TRUELY_ANNOTATE", "0")
+    scores = []
+    for batch in (32, 2, 3):
+        monkeypatch.setattr(model, "BATCH", batch)
+        dst = str(tmp_path / f"out{batch}.trlv")
+        scores.append(model.run(src, dst))
+        rd, _f, _w, _h = video_io.open_reader(dst)
+        assert rd.n == 40
+        for i in range(40):
+            ok, got = rd.read()
+            assert ok and np.array_equal(got, fr[i])            # un-annotated output = the decoded frames, in order
+    assert scores[0] == scores[1] == scores[2]
+    r = oracle.detect_embed(fr[::4])
+    assert scores[0] == oracle.drift_score(r["emb"], r["valid"], 40, fps)["score"]
+
+
+def test_run_nv12_device_ingest(engine, oracle, tmp_path, monkeypatch):
+    """A clip whose container yields NV12 (decoder output) is converted on the device (trl_ingest_nv12), sampled there and scored;
+    the written frames are the BGR conversion, byte for byte what the oracle's BT.601 restatement gives."""
+    from truely_amd import engine as eng_mod, model, video_io
+    from truely_amd.ingest import bgr_to_nv12
+    monkeypatch.setattr(eng_mod, "_default", engine)
+    monkeypatch.setattr(model, "BATCH", 3)
+    monkeypatch.setenv("TRUELY_ANNOTATE", "0")
+    H, W, fps = 180, 320, 30
+    nv = bgr_to_nv12(truely_amd.synthetic.synthetic_frames(22, H, W, seed=3))
+    src, dst = str(tmp_path / "in_nv12.trlv"), str(tmp_path / "out.trlv")
+    video_io.write_raw(src, nv, fps, pixfmt="nv12", size=(W, H))
+    score = model.run(src, dst)
+    bgr = np.stack([oracle.nv12_to_bgr(f, H, W) for f in nv])
+    r = oracle.detect_embed(bgr[::4])
+    assert score == oracle.drift_score(r["emb"], r["valid"], 22, fps)["score"]
+    rd, _f, _w, _h = video_io.open_reader(dst)
+    assert rd.n == 22 and rd.pixfmt == "bgr"
+    for i in range(22):
+        ok, got = rd.read()
+        assert ok and np.array_equal(got, bgr[i])
+
+
+def test_run_writes_annotations(engine, tmp_path, monkeypatch):
+    """Sampled frames that were compared with a predecessor carry a box (model.py:67-74); the others are untouched."""
+    from truely_amd import engine as eng_mod, model, video_io
+    monkeypatch.setattr(eng_mod, "_default", engine)
+    H, W, fps = 180, 320, 30
+    fr = truely_amd.synthetic.synthetic_frames(24, H, W, seed=3)
+    src, dst = str(tmp_path / "in.trlv"), str(tmp_path / "out.trlv")
+    video_io.write_raw(src, fr, fps)
+    model.run(src, dst)
+    out = engine.detect_embed(fr[::4])
+    valid = out["valid"].cpu().numpy()
+    rd, _f, _w, _h = video_io.open_reader(dst)
+    seen_prev, drawn = False, 0
+    for i in range(24):
+        ok, got = rd.read()
+        changed = not np.array_equal(got, fr[i])
+        if i % 4 == 0 and valid[i // 4] and seen_prev:
+            assert changed; drawn += 1
+        else:
+            assert not changed
+        if i % 4 == 0 and valid[i // 4]:
+            seen_prev = True
+    assert drawn >= 1

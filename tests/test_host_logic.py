@@ -162,3 +162,86 @@ def test_analysis_service_keeps_event_loop_free():
     svc.close()
     assert res == [1, 3, 2] and order[:3] == ["a", "bbb", "cc"]      # FIFO, one at a time
     assert ticks == 20 and svc.completed == 3                       # the loop was never blocked
+
+
+def test_rectangle_pixel_fixture():
+    """cv2.rectangle(img, (3, 2), (8, 6), c, 2) as restated in annotate.py: thickness 2 covers offsets -1..+1 around each edge
+    (3-pixel lines), clipped to the frame.  Hand-derived mask."""
+    from truely_amd import annotate
+    img = np.zeros((10, 12, 3), np.uint8)
+    annotate.rectangle(img, (3, 2), (8, 6), (0, 255, 0), 2)
+    exp = np.zeros((10, 12), bool)
+    exp[1:8, 2:10] = True            # outer bound: rows 2-1 .. 6+1, columns 3-1 .. 8+1
+    exp[4:5, 5:7] = False            # inner hole: rows 2+2 .. 6-2, columns 3+2 .. 8-2
+    assert np.array_equal(img[..., 1] == 255, exp) and not img[..., 0].any() and not img[..., 2].any()
+    img = np.zeros((6, 6, 3), np.uint8)
+    annotate.rectangle(img, (-5, -5), (20, 3), (9, 9, 9), 1)          # thickness 1, mostly outside: only the bottom edge is visible
+    assert (img[3] == 9).all() and not img[:3].any() and not img[4:].any()
+
+
+def test_put_text_hershey_style():
+    """Anti-aliased stroke text: ink stays inside the text box cv2.getTextSize would report, sits on the baseline at `org`, scales
+    with fontScale and blends (intermediate values exist)."""
+    from truely_amd import annotate
+    img = np.zeros((60, 420, 3), np.uint8)
+    annotate.put_text(img, "AI Detected - Frame 120", (10, 40), 1, (0, 0, 255), 2)
+    ink = img[..., 2] > 0
+    w, h = annotate.text_size("AI Detected - Frame 120", 1)
+    ys, xs = np.nonzero(ink)
+    assert xs.min() >= 10 - 2 and xs.max() <= 10 + w + 2 and ys.max() <= 40 + 2 and ys.min() >= 40 - h - 2
+    assert ys.max() >= 39                                              # strokes reach the baseline
+    assert ((img[..., 2] > 0) & (img[..., 2] < 255)).sum() > 50        # anti-aliased edges
+    assert not img[..., 0].any() and not img[..., 1].any()
+    small = np.zeros((60, 420, 3), np.uint8)
+    annotate.put_text(small, "Real Frame", (10, 40), 0.5, (0, 255, 0), 2)
+    ys2, xs2 = np.nonzero(small[..., 1] > 0)
+    assert (ys2.max() - ys2.min()) < 0.7 * (ys.max() - ys.min())      # half the scale
+    ref = np.zeros((60, 420, 3), np.uint8)
+    annotate.put_text(ref, "Real Frame", (10, 40), 0.5, (0, 255, 0), 2)
+    assert np.array_equal(small, ref)                                  # deterministic
+
+
+def test_async_writer_order_skip_and_errors(tmp_path):
+    from truely_amd import video_io
+    fr = np.random.default_rng(0).integers(0, 255, (7, 16, 20, 3), dtype=np.uint8)
+    path = str(tmp_path / "o.trlv")
+    w = video_io.AsyncWriter(video_io.RawWriter(path, 30, (20, 16)), annotate=False, depth=2)
+    for i in range(7):
+        w.put(fr[i].copy(), (i, (2, 2, 10, 10), True))                # notes ignored: annotate=False
+    w.close()
+    rd, fps, W, H = video_io.open_reader(path)
+    assert (rd.n, fps, W, H) == (7, 30, 20, 16)
+    for i in range(7):
+        assert np.array_equal(rd.read()[1], fr[i])
+    w = video_io.AsyncWriter(None)                                     # skipped stage: nothing written, nothing raised
+    w.put(fr[0]); w.close()
+    assert w.frames == 1
+
+    class Bad:
+        def write(self, f):
+            raise IOError("disk full")
+
+        def release(self):
+            pass
+    w = video_io.AsyncWriter(Bad())
+    for i in range(5):
+        w.put(fr[i])                                                   # must not dead-lock on a failed stage
+    with pytest.raises(IOError):
+        w.close()
+
+
+def test_nv12_container_roundtrip(tmp_path):
+    from truely_amd import video_io
+    from truely_amd.ingest import bgr_to_nv12
+    fr = np.random.default_rng(1).integers(0, 255, (3, 8, 12, 3), dtype=np.uint8)
+    nv = bgr_to_nv12(fr)
+    assert nv.shape == (3, 8 * 12 * 3 // 2)
+    path = str(tmp_path / "c.trlv")
+    video_io.write_raw(path, nv, 25.0, pixfmt="nv12", size=(12, 8))
+    rd, fps, W, H = video_io.open_reader(path)
+    assert (rd.pixfmt, fps, W, H, rd.n) == ("nv12", 25, 12, 8, 3)
+    for i in range(3):
+        assert np.array_equal(rd.read()[1], nv[i])
+    gray = np.full((1, 4, 4, 3), 128, np.uint8)                        # BT.601 limited range: mid grey -> Y = 126, U = V = 128
+    g = bgr_to_nv12(gray)[0]
+    assert (g[:16] == 126).all() and (g[16:] == 128).all()

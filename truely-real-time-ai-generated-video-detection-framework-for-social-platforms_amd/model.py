@@ -23,7 +23,7 @@ import torch
 from . import video_io
 from .engine import Engine, default_engine
 
-BATCH = 64   # sampled frames per device call inside run()
+BATCH = 32   # sampled frames per device call inside run(): the window holds BATCH * step decoded frames
 
 
 def analyze_video(frames, fps: int = 30, frame_count: int | None = None, engine: Engine | None = None,
@@ -49,6 +49,18 @@ def analyze_video(frames, fps: int = 30, frame_count: int | None = None, engine:
 
 
 def run(video_path_one: str, video_path_two: str) -> int:
+    """server/model.py::run, streaming: memory is bounded by ONE batch of decoded frames (BATCH sampled frames and the
+    frames between them), not by the clip -- a 10-minute 720p clip held in a Python list, as a literal port would, is ~50 GB.
+
+    Frames are decoded into a window; when the window holds BATCH sampled frames they go through ``trl_detect_embed``, the drift
+    state machine is re-run over every embedding seen so far (causal: a frame's flag depends only on earlier frames, so the
+    flags of the window are final), and the window's frames are handed to the decoupled writer (video_io.AsyncWriter: drawing +
+    encoding on their own thread).  Clips whose container yields NV12 (a hardware decoder's output) take the device ingest
+    path: the whole window is copied to the GPU through pinned memory as NV12 (1.5 B/pixel), converted to BGR there
+    (``trl_ingest_nv12``), the sampled frames are analysed in place and the BGR frames come back for the writer.
+
+    Environment: TRUELY_ANNOTATE=0 writes the frames without boxes / text; TRUELY_WRITE_OUTPUT=0 skips the output stage
+    (benchmarking only: the server requires a non-empty file, server.py:612-627)."""
     start_time = time.time()
     # model.py:20-22
     if not os.path.exists(video_path_one) or os.path.getsize(video_path_one) == 0:
@@ -64,52 +76,68 @@ def run(video_path_one: str, video_path_two: str) -> int:
         cap.release()
         return 0
     eng = default_engine()
-    out = video_io.open_writer(video_path_two, fps, (width, height), isinstance(cap, video_io.RawReader))
+    nv12 = getattr(cap, "pixfmt", "bgr") == "nv12"
+    write_out = os.environ.get("TRUELY_WRITE_OUTPUT", "1") != "0"
+    sink = video_io.open_writer(video_path_two, fps, (width, height), isinstance(cap, video_io.RawReader)) if write_out else None
+    writer = video_io.AsyncWriter(sink, annotate=os.environ.get("TRUELY_ANNOTATE", "1") != "0")
     step = max(1, int(fps / 7))   # model.py:40
     frame_count = 0
-    pending, pending_idx = [], []           # sampled frames waiting for the device
-    held = []                               # (index, frame) in decode order, written once annotated
-    embs, valids, rects = [], [], []
+    window, first = [], 0                   # decoded frames of the current window; index of window[0] in the clip
+    embs, valids = [], []                   # per-window device tensors (2 KB per sampled frame)
+    uploader = None
 
     def flush():
-        if not pending:
+        """Analyse the window's sampled frames, then release the window to the writer."""
+        nonlocal window, first, uploader
+        if not window:
             return
-        r = eng.detect_embed(np.stack(pending))
-        embs.append(r["emb"]); valids.append(r["valid"]); rects.append(r["rect"].cpu().numpy())
-        pending.clear(); pending_idx.clear()
+        off = (-first) % step                               # first sampled frame inside the window (model.py:46)
+        if nv12:
+            from .ingest import Nv12Uploader
+            if uploader is None:
+                uploader = Nv12Uploader(eng, height, width, BATCH * step)
+            bgr_dev = uploader.upload(np.stack(window), 1)  # every frame of the window, converted on the device
+            sampled = bgr_dev[off::step].contiguous()
+        else:
+            bgr_dev = None
+            sampled = np.stack(window[off::step]) if len(window) > off else None
+        notes = {}
+        if sampled is not None and len(sampled) > 0:
+            r = eng.detect_embed(sampled)
+            embs.append(r["emb"]); valids.append(r["valid"])
+            emb = torch.cat(embs); valid = torch.cat(valids)
+            d = eng.drift_score(emb, valid, first + len(window), fps)   # model.py:60-66 over everything seen so far
+            k0 = emb.shape[0] - r["emb"].shape[0]
+            sims = d["sims"][k0:].cpu().numpy(); flags = d["flags"][k0:].cpu().numpy()
+            vmask = r["valid"].cpu().numpy(); rect = r["rect"].cpu().numpy()
+            for j in range(len(vmask)):
+                if vmask[j] and sims[j] <= 1.5:             # a face with a previous embedding (model.py:60,67-74)
+                    notes[off + j * step] = (first + off + j * step, rect[j], bool(flags[j]))
+        if write_out:
+            frames = bgr_dev.cpu().numpy() if nv12 else window
+            for i in range(len(window)):
+                writer.put(frames[i], notes.get(i))
+        first += len(window)
+        window = []
 
     while cap.isOpened():
         ret, frame = cap.read()
         if not ret:
             break
-        if frame_count % step == 0:     # model.py:46
-            pending.append(frame); pending_idx.append(frame_count)
-            if len(pending) == BATCH:
-                flush()
-        held.append(frame)
+        window.append(frame)
         frame_count += 1
+        if len(window) == BATCH * step:
+            flush()
     flush()
     cap.release()
+    writer.close()
     if frame_count == 0:    # model.py:83-85
-        out.release()
         print("Error: No frames were processed")
         return 0
-    emb = torch.cat(embs); valid = torch.cat(valids); rect = np.concatenate(rects)
-    d = eng.drift_score(emb, valid, frame_count, fps)   # model.py:60-66,86-95
-    sims = d["sims"].cpu().numpy(); flags = d["flags"].cpu().numpy(); vmask = valid.cpu().numpy()
-    # model.py:67-74,77: annotate sampled frames that had a previous embedding, write every frame
-    for i, frame in enumerate(held):
-        if i % step == 0:
-            j = i // step
-            if vmask[j] and sims[j] <= 1.5:
-                x0, y0, x1, y1 = (int(v) for v in rect[j])
-                if flags[j]:
-                    video_io.draw_box(frame, x0, y0, x1, y1, (0, 0, 255), 2)
-                    video_io.put_text(frame, f"AI Detected - Frame {i}", (10, 30), 1, (0, 0, 255), 2)
-                else:
-                    video_io.draw_box(frame, x0, y0, x1, y1, (0, 255, 0), 2)
-                    video_io.put_text(frame, "Real Frame", (x0, y0 - 10), 0.5, (0, 255, 0), 2)
-        out.write(frame)
-    out.release()
+    if embs:
+        d = eng.drift_score(torch.cat(embs), torch.cat(valids), frame_count, fps)   # model.py:86-95 with the final frame count
+        score = int(d["score"])
+    else:
+        score = 0
     print(f"Total Execution Time: {time.time() - start_time} seconds")   # model.py:78-80
-    return int(d["score"])
+    return score

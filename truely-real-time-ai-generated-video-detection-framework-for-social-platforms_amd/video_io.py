@@ -5,15 +5,22 @@ The reference decodes with ``cv2.VideoCapture`` and re-encodes every frame with
 the build environment, so two back-ends exist behind the same tiny interface:
 
 * ``cv2`` when importable (real .mp4 in, annotated .mp4 out, like the reference);
-* the raw "TRLV" container (uint8 BGR frames + fps header) used by the tests and the benchmark.
-GPU-side decode is SURVEY section 8(f) rank 1 ("next"), not built yet.
+* the raw "TRLV" container (fps header + uint8 frames, BGR or -- what a hardware decoder hands over -- NV12) used by the
+  tests and the benchmark.  NV12 clips take the device ingest path of ``model.run``.
+``AsyncWriter`` is the decoupled, skippable annotated-output stage: drawing and encoding run on their
+own thread behind a bounded queue, so the analysis loop never waits for the encoder (the reference draws and encodes inline,
+server/model.py:67-77).
 """
 from __future__ import annotations
 
 import os
+import queue
 import struct
+import threading
 
 import numpy as np
+
+from . import annotate as _annotate
 
 _MAGIC = b"TRLV0001"
 
@@ -32,29 +39,34 @@ class RawReader:
             raise ValueError("not a TRLV file")
         self.n, self.height, self.width = struct.unpack("<III", head[8:20])
         (self.fps_f,) = struct.unpack("<d", head[20:28])
+        (fmt,) = struct.unpack("<I", head[28:32])
+        self.pixfmt = "nv12" if fmt == 1 else "bgr"
+        self.frame_bytes = self.height * self.width * 3 // (2 if fmt == 1 else 1)
         self.i = 0
 
     def isOpened(self):
         return True
 
     def read(self):
+        """(ok, frame): BGR (H, W, 3) for a BGR clip, the flat NV12 frame (H*W*3/2,) for an NV12 clip."""
         if self.i >= self.n:
             return False, None
-        buf = self.f.read(self.height * self.width * 3)
-        if len(buf) < self.height * self.width * 3:
+        buf = self.f.read(self.frame_bytes)
+        if len(buf) < self.frame_bytes:
             return False, None
         self.i += 1
-        return True, np.frombuffer(buf, np.uint8).reshape(self.height, self.width, 3).copy()
+        a = np.frombuffer(buf, np.uint8)
+        return True, (a.copy() if self.pixfmt == "nv12" else a.reshape(self.height, self.width, 3).copy())
 
     def release(self):
         self.f.close()
 
 
 class RawWriter:
-    def __init__(self, path, fps, size):
+    def __init__(self, path, fps, size, pixfmt: str = "bgr"):
         self.path, self.w, self.h, self.n = path, size[0], size[1], 0
         self.f = open(path, "wb")
-        self.f.write(_MAGIC + struct.pack("<IIId", 0, self.h, self.w, float(fps)) + b"\0" * 4)
+        self.f.write(_MAGIC + struct.pack("<IIIdI", 0, self.h, self.w, float(fps), 1 if pixfmt == "nv12" else 0))
 
     def write(self, frame):
         self.f.write(np.ascontiguousarray(frame, np.uint8).tobytes())
@@ -66,11 +78,56 @@ class RawWriter:
         self.f.close()
 
 
-def write_raw(path, frames: np.ndarray, fps: float):
-    w = RawWriter(path, fps, (frames.shape[2], frames.shape[1]))
+def write_raw(path, frames: np.ndarray, fps: float, pixfmt: str = "bgr", size=None):
+    """BGR clip: frames (n, H, W, 3).  NV12 clip: frames (n, H*W*3/2) plus size=(W, H)."""
+    w = RawWriter(path, fps, size or (frames.shape[2], frames.shape[1]), pixfmt)
     for fr in frames:
         w.write(fr)
     w.release()
+
+
+class AsyncWriter:
+    """Decoupled annotated-output stage.  ``put(frame, note)`` hands a frame (and, for sampled frames that were compared with
+    their predecessor, ``note = (frame_index, rect, flagged)``) to a worker thread that draws (annotate.py) and encodes.
+    ``annotate=False`` skips the drawing, ``sink=None`` skips the stage altogether (benchmarks); the queue is bounded, so a slow
+    encoder applies back-pressure instead of growing memory."""
+
+    def __init__(self, sink, annotate: bool = True, depth: int = 64):
+        self.sink, self.annotate, self.frames = sink, annotate, 0
+        self.err = None
+        self.q = queue.Queue(maxsize=depth)
+        self.th = threading.Thread(target=self._work, name="truely-writer", daemon=True) if sink is not None else None
+        if self.th:
+            self.th.start()
+
+    def _work(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if self.err is not None:
+                continue                                  # keep draining so the producer never blocks on a dead stage
+            try:
+                frame, note = item
+                if note is not None and self.annotate:
+                    _annotate.annotate(frame, *note)
+                self.sink.write(frame)
+            except BaseException as e:                    # surfaced by close()
+                self.err = e
+
+    def put(self, frame, note=None):
+        self.frames += 1
+        if self.th:
+            self.q.put((frame, note))
+
+    def close(self):
+        if self.th:
+            self.q.put(None)
+            self.th.join()
+        if self.sink is not None:
+            self.sink.release()
+        if self.err is not None:
+            raise self.err
 
 
 def open_reader(path):
@@ -95,23 +152,8 @@ def open_writer(path, fps, size, like_raw: bool):
 
 
 def draw_box(frame: np.ndarray, x0, y0, x1, y1, color, thickness=2):
-    """cv2.rectangle stand-in (outline centred on the box edge, clipped to the frame)."""
-    if cv2 is not None:  # pragma: no cover
-        cv2.rectangle(frame, (x0, y0), (x1, y1), color, thickness)
-        return
-    H, W = frame.shape[:2]
-    t0, t1 = thickness // 2, thickness - thickness // 2
-    def span(a, lo, hi):
-        return max(lo, a - t0), min(hi, a + t1)
-    ya, yb = span(y0, 0, H); yc, yd = span(y1, 0, H)
-    xa, xb = span(x0, 0, W); xc, xd = span(x1, 0, W)
-    xs, xe = max(0, x0 - t0), min(W, x1 + t1)
-    ys, ye = max(0, y0 - t0), min(H, y1 + t1)
-    frame[ya:yb, xs:xe] = color; frame[yc:yd, xs:xe] = color
-    frame[ys:ye, xa:xb] = color; frame[ys:ye, xc:xd] = color
+    _annotate.rectangle(frame, (x0, y0), (x1, y1), color, thickness)
 
 
 def put_text(frame, text, org, scale, color, thickness):
-    if cv2 is not None:  # pragma: no cover
-        cv2.putText(frame, text, org, cv2.FONT_HERSHEY_SIMPLEX, scale, color, thickness, cv2.LINE_AA)
-    # without OpenCV the Hershey font is unavailable; the label is skipped (annotation is row 8(f)-2)
+    _annotate.put_text(frame, text, org, scale, color, thickness)
