@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "trl_ctx.h"
 
@@ -45,7 +46,8 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
     TRL_HIP(hipSetDevice(cfg->device));
     trl_ctx* c = new trl_ctx();
     c->cfg = *cfg;
-    if (hipMalloc((void**)&c->pnet_clk, 16) != hipSuccess) c->pnet_clk = nullptr;
+    // diagnostic only: the clocked PNet instantiation (device-wall-clock span of the launch) runs when TRL_PNET_CLOCK is set
+    if (getenv("TRL_PNET_CLOCK") && hipMalloc((void**)&c->pnet_clk, 16) != hipSuccess) c->pnet_clk = nullptr;
     TRL_HIP(hipMalloc((void**)&c->pnet_cursor, 64));
     if (hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess) { delete c; trl_set_error("hipHostMalloc failed"); return TRL_ERR_HIP; }
     memset(c->h_pinned, 0, 256);

@@ -13,6 +13,10 @@
 // -ffp-contract=off), so boxes / keep masks are bit-identical to the oracle.
 #include "trl_ctx.h"
 
+// R-/O-Net candidates per launch set: one set covers a 256-frame batch (31 k / 8.5 k candidates), so no near-empty third chunk is
+// launched; scratch per chunk = 100 KB / 640 KB per candidate (5 / 8 GB at the cap, of 288 GB)
+constexpr int TRL_CH2 = 49152, TRL_CH3 = 12288;
+
 namespace {
 
 __device__ __forceinline__ uint32_t f2ord(float f) {   // ascending-order preserving map
@@ -679,7 +683,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         const long long lim = (long long)n * capF;
         c->cap_t2 = (int)(c2 < lim ? c2 : lim);
         c->cap_t3 = (int)(c3 < lim ? c3 : lim);
-        const int ch2 = c->cap_t2 < 16384 ? c->cap_t2 : 16384, ch3 = c->cap_t3 < 4096 ? c->cap_t3 : 4096;
+        const int ch2 = c->cap_t2 < TRL_CH2 ? c->cap_t2 : TRL_CH2, ch3 = c->cap_t3 < TRL_CH3 ? c->cap_t3 : TRL_CH3;
         size_t need_x = (size_t)c->cap_t2 * 24 + (size_t)ch2 * (24 * 24 * 3 * 4 + 100 * 1024) + (1u << 20);
         const size_t need3 = (size_t)c->cap_t3 * 64 + (size_t)ch3 * (48 * 48 * 3 * 4 + 640 * 1024) + (1u << 20);
         if (need3 > need_x) need_x = need3;
@@ -742,7 +746,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     X.reset();   // stream order keeps the PNet workspace alive until its kernels are done: reuse needs no host sync
     float* out6 = (float*)X.alloc((size_t)cap2 * 24);
     {
-        const int CH = 16384;
+        const int CH = TRL_CH2;
         const size_t mk = X.off;
         for (int t0 = 0; t0 < cap2; t0 += CH) {
             const int nc = (cap2 - t0 < CH) ? cap2 - t0 : CH;
@@ -764,7 +768,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     X.reset();
     float* out16 = (float*)X.alloc((size_t)cap3 * 64);
     {
-        const int CH = 4096;
+        const int CH = TRL_CH3;
         const size_t mk = X.off;
         for (int t0 = 0; t0 < cap3; t0 += CH) {
             const int nc = (cap3 - t0 < CH) ? cap3 - t0 : CH;

@@ -378,7 +378,9 @@ __device__ __forceinline__ int koff(int s, int kq, int e1, int e2, int e3) {
 template <bool UNIT>
 __device__ __forceinline__ float prelu_t(float v, float sl) { return UNIT ? fmaxf(v, sl * v) : prelu(v, sl); }
 
-template <bool UNIT>
+// CLK: diagnostic instantiation that records the launch's execution span on the device wall clock (TRL_PNET_CLOCK=1);
+// the production instantiation carries no instrumentation.
+template <bool UNIT, bool CLK>
 __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every M-tile index below is SALU work
-    if (tid == 0 && a.clk) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());   // execution span of the launch, queueing excluded
+    if (CLK && tid == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());   // execution span of the launch, queueing excluded
     const int l15 = lane & 15, kq = lane >> 4;      // 16x16x4 operand coordinates
     const int l31 = lane & 31, hh = lane >> 5;      // 32x32x2 operand coordinates
 
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         }
         __syncthreads();   // RA / RB are rewritten by the next tile
     }
-    if (tid == 0 && a.clk) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
+    if (CLK && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
 
 }  // namespace
@@ -1163,7 +1165,6 @@ int trl_pyramid_export(trl_ctx* c, const uint8_t* d_frame, int H, int W, int lev
 int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipEvent_t* ev, hipStream_t s) {
     PnetArgs a;
     TRL_CHECK(build_pyramid(c, d_frames, n, H, W, a, ev, s));
-    if (ev) TRL_HIP(hipEventRecord(ev[2], s));
     const int total_tiles = a.tiles_per_frame * n;
     int grid = 256 * 2;                       // 2 resident workgroups per CU (<= 256 VGPRs)
     if (grid > ((total_tiles + 7) / 8) * 8) grid = ((total_tiles + 7) / 8) * 8;
@@ -1173,8 +1174,14 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         TRL_HIP(hipMemsetAsync(c->pnet_clk, 0xFF, 8, s));
         TRL_HIP(hipMemsetAsync(c->pnet_clk + 1, 0, 8, s));
     }
-    if (c->pnet_unit) k_pnet_fused<true><<<grid, 256, 0, s>>>(a);
-    else k_pnet_fused<false><<<grid, 256, 0, s>>>(a);
+    if (ev) TRL_HIP(hipEventRecord(ev[2], s));   // the event pair brackets the kernel alone (HIP events on the launch's stream)
+    if (c->pnet_clk) {
+        if (c->pnet_unit) k_pnet_fused<true, true><<<grid, 256, 0, s>>>(a);
+        else k_pnet_fused<false, true><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (c->pnet_unit) k_pnet_fused<true, false><<<grid, 256, 0, s>>>(a);
+        else k_pnet_fused<false, false><<<grid, 256, 0, s>>>(a);
+    }
     TRL_LAUNCH_CHECK();
     if (ev) TRL_HIP(hipEventRecord(ev[3], s));
     return TRL_OK;
