@@ -4,7 +4,7 @@
 // Per batch of frames: one k_pyramid launch per (level, Infinity-Cache-sized frame chunk), then ONE fused launch.
 //
 //  k_pyramid      u8 BGR frames -> every pyramid level, imresample (F.interpolate mode="area") +
-//                 (x-127.5)*0.0078125, stored as float4 {b,g,r,0} per pixel (streamed past the caches).  One
+//                 (x-127.5)*0.0078125, stored as three floats {b,g,r} per pixel (12 B, streamed past the caches).  One
 //                 lane (fine levels) or lane group (coarse levels) per output pixel, dword-aligned 16/12-byte
 //                 loads + v_dot4 byte sums (integer-exact, order independent), bin edges by exact multiply-high
 //                 division, bin mean by the exhaustively verified reciprocal division (pyr_div).
@@ -47,10 +47,14 @@ constexpr int REGION_B = 4 * 32 * ST_LD;             // 4224 floats: pooled conv
 static_assert(3 * 7 * 256 <= REGION_A, "input tile (+ the 28 overhang pixels of the 7x256 copy) fits region A");
 static_assert(P1_T * P1_T * 10 <= REGION_B, "pooled tile fits region B");
 
+// One pyramid pixel = three floats (a fourth padding float would be 25 % of the pyramid's write + read traffic).
+struct PyrPx { float b, g, r; };
+typedef float f32x3_nt __attribute__((ext_vector_type(3), aligned(4)));
+
 struct PLevel {
     int h, w, oh, ow;        // level size, PNet map size
     int tiles_x, tile0;      // tiles per row, first tile index of the level inside a frame
-    int pix0;                // float4 offset of the level inside a frame's pyramid
+    int pix0;                // pixel offset of the level inside a frame's pyramid
     int pix_pad;             // h*w rounded up to 64 (pyramid slots of the level)
     int gshift, work0;       // pyramid kernel: log2(lanes per pixel), first thread of the level inside a frame
     int ytab0, xtab0;        // offsets of the level's row / column bin-edge tables
@@ -66,7 +70,7 @@ struct PLevel {
     float scale;
 };
 struct PnetArgs {
-    const float4* pyr; long long pyr_stride;   // float4 per frame
+    const PyrPx* pyr; long long pyr_stride;    // pixels per frame
     int n_frames, L, tiles_per_frame, H, W;
     unsigned tpf_magic;                        // ceil(2^32 / tiles_per_frame)
     long long work_per_frame;                  // pyramid kernel threads per frame
@@ -124,10 +128,10 @@ __device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF
 // The pyramid is written once and read once, much later, by the PNet kernel: stream it past the caches so the source
 // frame (re-read by every level) keeps its L2 / Infinity Cache lines.
 typedef float f32x4_nt __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void pyr_store(float4* dst, const float4& v) {
-    static_assert(sizeof(float4) == sizeof(f32x4_nt), "layout");
-    f32x4_nt t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<f32x4_nt*>(dst));
+__device__ __forceinline__ void pyr_store(PyrPx* dst, const float4& v) {
+    static_assert(sizeof(PyrPx) == 12, "layout");
+    f32x3_nt t = {v.x, v.y, v.z};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x3_nt*>(dst));
 }
 
 // Correctly rounded a / b from r = RN(1/b) (Markstein): q0 = RN(a r), e = a - b q0 (exact in one fma), q = RN(q0 + e r).
@@ -156,7 +160,7 @@ struct PyrArgs { int H, W, n_frames, f0; long long pyr_stride; PLevel g; };
 // threads q = q0, q0 + qstep, ... of level g of frame f
 template <int MODE, typename A>
 __device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ frames, const A& a, const PLevel& g, const uint32_t* __restrict__ tab,
-                                          float4* __restrict__ pyr, int f, int q0, int qstep) {
+                                          PyrPx* __restrict__ pyr, int f, int q0, int qstep) {
     const int per_frame = g.pix_pad << g.gshift;            // threads of this level per frame
     constexpr int mode = MODE;
     const uint32_t* base32 = reinterpret_cast<const uint32_t*>(frames);
@@ -255,7 +259,7 @@ __device__ __forceinline__ void pyr_level(const uint8_t* __restrict__ frames, co
 // loads in flight per wave are what counts (specialising on ROWS / FOUR keeps it under 64 VGPRs).
 template <int ROWS, bool FOUR, typename A>
 __device__ __forceinline__ void pyr_level0(const uint8_t* __restrict__ frames, const A& a, const PLevel& g, const uint32_t* __restrict__ tab,
-                                           float4* __restrict__ pyr, int f, int q0, int qstep) {
+                                           PyrPx* __restrict__ pyr, int f, int q0, int qstep) {
     constexpr int ND = FOUR ? 5 : 4;                                                 // dwords fetched per row
     const long long fbase = (long long)f * a.H * a.W * 3;
     const long long total = (long long)a.n_frames * a.H * a.W * 3;
@@ -348,7 +352,7 @@ __device__ __forceinline__ void pyr_level0(const uint8_t* __restrict__ frames, c
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ frames, PyrArgs a, const uint32_t* __restrict__ tab,
-                                                 float4* __restrict__ pyr) {
+                                                 PyrPx* __restrict__ pyr) {
     if (MODE == 0) pyr_level0<5, true>(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     else pyr_level<MODE>(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint8_t* __restrict__ fra
 // mode 0, specialised on the level's row count / dword count (register budget = occupancy = loads in flight)
 template <int ROWS, bool FOUR>
 __global__ __launch_bounds__(256) void k_pyramid0(const uint8_t* __restrict__ frames, PyrArgs a, const uint32_t* __restrict__ tab,
-                                                  float4* __restrict__ pyr) {
+                                                  PyrPx* __restrict__ pyr) {
     pyr_level0<ROWS, FOUR>(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
@@ -464,15 +468,15 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         const PLevel& g = a.lv[t.l];
         const int gy0 = t.ty * 2 * TS, gx0 = t.tx * 2 * TS;
         const char* srcb = reinterpret_cast<const char*>(a.pyr + (long long)t.f * a.pyr_stride + g.pix0 + (long long)gy0 * g.w + gx0);
-        const int w16 = g.w * 16;
+        const int w16 = g.w * 12;                  // bytes per pyramid row (12 B pixels)
         const int hrem = g.h - gy0, wrem = g.w - gx0;
         if (hrem >= IN_T && wrem >= IN_T) {
-            const unsigned v0 = (unsigned)(pin_iy0 * w16 + pin_ix0 * 16);
+            const unsigned v0 = (unsigned)(pin_iy0 * w16 + pin_ix0 * 12);
 #pragma unroll
             for (int i = 0; i < 7; i++) {
-                unsigned vo = v0 + (unsigned)(i * (6 * w16 + 64)) + ((pin_ix0 >= IN_T - 4 * i) ? (unsigned)(w16 - IN_T * 16) : 0u);
+                unsigned vo = v0 + (unsigned)(i * (6 * w16 + 48)) + ((pin_ix0 >= IN_T - 4 * i) ? (unsigned)(w16 - IN_T * 12) : 0u);
                 if (i == 6) vo = (tid < IN_T * IN_T - 6 * 256) ? vo : 0u;     // p >= 42*42: reload pixel 0 (lands in the RA tail)
-                pre[i] = *reinterpret_cast<const float4*>(srcb + vo);
+                { const f32x3_nt v3 = *reinterpret_cast<const f32x3_nt*>(srcb + vo); pre[i] = make_float4(v3[0], v3[1], v3[2], 0.f); }
             }
         } else {
 #pragma unroll
@@ -480,7 +484,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 const bool wrap = pin_ix0 >= IN_T - 4 * i;
                 const int iy = pin_iy0 + 6 * i + (wrap ? 1 : 0), ix = pin_ix0 + 4 * i - (wrap ? IN_T : 0);
                 const bool ok = iy < hrem && ix < wrem && (i < 6 || tid < IN_T * IN_T - 6 * 256);
-                pre[i] = ok ? *reinterpret_cast<const float4*>(srcb + (unsigned)(iy * w16 + ix * 16)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) { const f32x3_nt v3 = *reinterpret_cast<const f32x3_nt*>(srcb + (unsigned)(iy * w16 + ix * 12)); pre[i] = make_float4(v3[0], v3[1], v3[2], 0.f); }
             }
         }
     };
@@ -844,7 +849,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
 size_t trl_pnet_fused_bytes(trl_ctx* c, int n, int H, int W) {
     PnetArgs a;
     if (fill_args(c, n, H, W, a) != TRL_OK) return 0;
-    return (size_t)a.pyr_stride * n * sizeof(float4) + 4096;
+    return (size_t)a.pyr_stride * n * sizeof(PyrPx) + 4096;
 }
 
 // All pyramid levels of all n frames: pyramid kernel + one persistent fused launch.
@@ -886,7 +891,7 @@ __device__ __forceinline__ float stream_norm(unsigned s, int kh, int kw, const S
 constexpr int STAB = 6144;              // bin-edge words of the coarse levels kept in LDS (rows + columns of every level)
 template <int NL>
 __global__ __launch_bounds__(256) void k_pyramid_stream(const uint8_t* __restrict__ frames, PyrStreamArgs a, const uint32_t* __restrict__ gtab,
-                                                        float4* __restrict__ pyr) {
+                                                        PyrPx* __restrict__ pyr) {
     __shared__ unsigned colbuf[SBYTES];
     __shared__ uint32_t tab[STAB];          // the levels' edge tables, re-based: level l rows at ty0[l], columns at tx0[l]
     const int tid = threadIdx.x;
@@ -1064,7 +1069,7 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
         TRL_HIP(hipMemcpy(c->pyr_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
         c->pyr_tab_H = H; c->pyr_tab_W = W;
     }
-    float4* pyr = (float4*)c->scratch.alloc((size_t)a.pyr_stride * n * sizeof(float4));
+    PyrPx* pyr = (PyrPx*)c->scratch.alloc((size_t)a.pyr_stride * n * sizeof(PyrPx));
     if (!pyr) { trl_set_error("pyramid workspace"); return TRL_ERR_STATE; }
     a.pyr = pyr;
     if (ev) TRL_HIP(hipEventRecord(ev[0], s));
@@ -1145,11 +1150,11 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
 }
 
 // debug / test hook: level `level` of ONE frame's pyramid exactly as the fused PNet kernel reads it -> d_out [h][w][3]
-__global__ void k_export_level(const float4* __restrict__ pyr, int npix, float* __restrict__ out) {
+__global__ void k_export_level(const PyrPx* __restrict__ pyr, int npix, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
-    const float4 v = pyr[i];
-    out[3 * i + 0] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+    const PyrPx v = pyr[i];
+    out[3 * i + 0] = v.b; out[3 * i + 1] = v.g; out[3 * i + 2] = v.r;
 }
 int trl_pyramid_export(trl_ctx* c, const uint8_t* d_frame, int H, int W, int level, float* d_out, int* h, int* w, hipStream_t s) {
     PnetArgs a;
