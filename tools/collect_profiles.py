@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Builds profiles/round1_* from gpurun_out/refresh/ (written by tools/refresh_profiles.sh on the GPU box).
+"""Builds profiles/<tag>_* from gpurun_out/refresh/ (written by tools/refresh_profiles.sh on the GPU box).
 
-  python tools/collect_profiles.py [tag]        # tag defaults to round1
+  python tools/collect_profiles.py [tag]        # tag defaults to round2
 """
 import csv
 import json
@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
 
 
 def pmc_rows(path, counter):
@@ -37,9 +37,26 @@ def main():
     shutil.copy(os.path.join(SRC, "stats2", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats.csv"))            # default command
     shutil.copy(os.path.join(SRC, "stats", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats_inflight1.csv"))   # --in-flight 1
     shutil.copy(os.path.join(SRC, "bench_inflight1.json"), os.path.join(DST, f"{tag}_bench_inflight1.json"))
-    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_summary.py"), os.path.join(SRC, "stats", "s_kernel_trace.csv")],
+    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), os.path.join(SRC, "stats", "s_kernel_trace.csv"), "2", "--all"],
                           capture_output=True, text=True, check=True).stdout
-    open(os.path.join(DST, f"{tag}_last_step_summary.txt"), "w").write(summ)
+    open(os.path.join(DST, f"{tag}_step_timeline_inflight1.txt"), "w").write(summ)
+    for name in ("bench_sustained", "bench_config2", "bench_config4", "bench_prelu_general", "bench_ingest_nv12", "bench_gloo2_sharded", "bench_gloo2_streams"):
+        src = os.path.join(SRC, name + ".json")
+        if os.path.exists(src) and os.path.getsize(src) > 0:
+            shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
+    for sub, out in (("stats_c2", "config2_kernel_stats_inflight1.csv"), ("stats_c4", "config4_kernel_stats_inflight1.csv")):
+        src = os.path.join(SRC, sub, "s_kernel_stats.csv")
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(DST, f"{tag}_{out}"))
+    for sub in ("sq1", "sq2"):
+        src = os.path.join(SRC, sub, "p_counter_collection.csv")
+        if os.path.exists(src):
+            txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), src], capture_output=True, text=True, check=True).stdout
+            open(os.path.join(DST, f"{tag}_sq_pmc_{sub}.txt"), "w").write(txt)
+    for name in ("facenet_ms.txt", "facenet_stamps.txt"):
+        src = os.path.join(SRC, name)
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(DST, f"{tag}_{name}"))
     per_launch = {}
     for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         rows = pmc_rows(os.path.join(SRC, sub, "p_counter_collection.csv"), counter)
@@ -49,6 +66,13 @@ def main():
                 f.write(f"{d},{n},{counter},{v:.6f}\n")
         pn = [v for d, n, v in rows if "k_pnet_fused" in n]
         per_launch[counter] = sum(pn) / len(pn)
+    # pyramid kernels of one step (k_pyramid0 / k_pyramid_stream dispatches between two k_pnet_fused dispatches)
+    pyr_hbm = 0.0
+    for counter, sub, mul in (("FETCH_SIZE", "fetch", 2.0), ("WRITE_SIZE", "write", 1.0)):
+        rows = pmc_rows(os.path.join(SRC, sub, "p_counter_collection.csv"), counter)
+        pn = [d for d, n, v in rows if "k_pnet_fused" in n]
+        if len(pn) >= 2:
+            pyr_hbm += mul * 1024.0 * sum(v for d, n, v in rows if "k_pyramid" in n and pn[-2] < d < pn[-1])
     bench = json.loads(open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1])
     hbm = (2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024.0
     traffic = {
@@ -58,8 +82,9 @@ def main():
         "WRITE_SIZE_KB_per_launch": per_launch["WRITE_SIZE"],
         "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced 16 B/lane reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact",
         "hbm_bytes_per_launch": hbm,
-        "algorithmic_read_bytes": 2742837248,   # 256 frames x 669,638 pyramid pixels (720p, 11 levels, 64-padded) x 16 B
-        "note": "the pyramid (float4 per pixel) is read once; the 42x42 input tiles overlap by 1.72x and most of that halo is served by L2",
+        "pyramid_read_bytes": 2057127936,   # 256 frames x 669,638 pyramid pixels (720p, 11 levels, 64-padded) x 12 B
+        "note": "the pyramid (three floats per pixel) is read once; the 42x42 input tiles overlap by 1.72x and most of that halo is served by L2",
+        "pyramid_kernels_hbm_bytes_per_step": pyr_hbm,
     }
     json.dump(traffic, open(os.path.join(DST, f"{tag}_pnet_traffic.json"), "w"), indent=1)
     print(json.dumps(bench)[:600])

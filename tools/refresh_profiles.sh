@@ -1,22 +1,34 @@
 #!/bin/bash
-# Regenerates the evidence under gpurun_out/ that profiles/ is built from.  Run ON the GPU box:
-#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh'
-# then, back in the container:  python tools/collect_profiles.py
-# PMC passes are separate runs with --kernel-trace only (never combined with --stats / sys-trace).
-# bench.py keeps two batches in flight by default; the per-step kernel breakdown and the PMC traffic are taken with one
-# batch in flight (--in-flight 1) so that a step's launches are not interleaved with another context's.
-set -e
+# Regenerates the evidence under gpurun_out/refresh/ that profiles/round2_* is built from.  Run ON the GPU box:
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh'
+# then, back in the container:  python tools/collect_profiles.py round2
+# PMC passes are separate runs with --kernel-trace only (never combined with --stats / sys-trace).  The per-step kernel breakdown,
+# the timeline and the PMC passes use one batch in flight (--in-flight 1) so that a step's launches are not interleaved with
+# another context's; the headline bench keeps the default two.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh
 rm -rf $O && mkdir -p $O
-timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err
-echo "bench done"; cat $O/bench.json
-timeout -k 10 300 python bench.py --in-flight 1 --no-cpu-baseline > $O/bench_inflight1.json 2> $O/bench_inflight1.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats2 -o s -f csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/stats2.log 2>&1
-echo "stats (default command) done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o s -f csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 > $O/stats.log 2>&1
-echo "stats (one batch in flight) done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p -f csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --in-flight 1 > $O/fetch.log 2>&1
-echo "fetch done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p -f csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --in-flight 1 > $O/write.log 2>&1
-echo "write done"
+B="--no-cpu-baseline"
+timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench done"; cut -c1-300 $O/bench.json
+timeout -k 10 300 python bench.py --in-flight 1 $B > $O/bench_inflight1.json 2> $O/bench_inflight1.err
+timeout -k 10 300 python bench.py --steps 400 --warmup 5 $B > $O/bench_sustained.json 2> $O/bench_sustained.err; echo "sustained done"
+timeout -k 10 300 python bench.py --config 2 --steps 10 --warmup 2 $B > $O/bench_config2.json 2> $O/bench_config2.err
+timeout -k 10 300 python bench.py --config 4 --steps 6 --warmup 2 $B > $O/bench_config4.json 2> $O/bench_config4.err
+timeout -k 10 300 python bench.py --prelu general --steps 10 $B > $O/bench_prelu_general.json 2> $O/bench_prelu_general.err
+timeout -k 10 300 python bench.py --ingest nv12 --steps 10 $B > $O/bench_ingest_nv12.json 2> $O/bench_ingest_nv12.err
+timeout -k 10 300 python bench.py --gpus 2 --backend gloo --steps 6 $B > $O/bench_gloo2_sharded.json 2> $O/bench_gloo2_sharded.err
+timeout -k 10 300 python bench.py --gpus 2 --backend gloo --mode streams --steps 6 $B > $O/bench_gloo2_streams.json 2> $O/bench_gloo2_streams.err
+echo "bench variants done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats2 -o s -f csv -- python3 bench.py --steps 6 --warmup 2 $B > $O/stats2.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o s -f csv -- python3 bench.py --steps 5 --warmup 2 $B --in-flight 1 > $O/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_c2 -o s -f csv -- python3 bench.py --config 2 --steps 4 --warmup 1 $B --in-flight 1 > $O/stats_c2.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_c4 -o s -f csv -- python3 bench.py --config 4 --steps 3 --warmup 1 $B --in-flight 1 > $O/stats_c4.log 2>&1
+echo "stats done"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p -f csv -- python3 bench.py --steps 2 --warmup 1 $B --in-flight 1 > $O/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p -f csv -- python3 bench.py --steps 2 --warmup 1 $B --in-flight 1 > $O/write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O/sq1 -o p -f csv -- python3 bench.py --steps 2 --warmup 1 $B --in-flight 1 > $O/sq1.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/sq2 -o p -f csv -- python3 bench.py --steps 2 --warmup 1 $B --in-flight 1 > $O/sq2.log 2>&1
+echo "pmc done"
+timeout -k 10 200 python tools/time_facenet.py > $O/facenet_ms.txt 2>&1
+timeout -k 10 200 python tools/fn_stamps.py 2 5 16 58 60 61 2>&1 | grep -E "launch|fn stamps" > $O/facenet_stamps.txt
+echo "facenet done"
