@@ -131,6 +131,9 @@ int  trl_debug_level_counts(trl_ctx* ctx, int frame, int32_t* h_cand, int32_t* h
  * rows of 40 bytes {x1,y1,x2,y2,score,r0,r1,r2,r3 : f32; cell : i32}, cell = y*ow + x of the PNet output map.  With
  * thr0 = 0 every cell is a candidate, so this reads the fused kernel's own probability / regression maps. */
 int  trl_debug_level_cands(trl_ctx* ctx, int frame, int level, void* h_rows, int max_rows, int* n_out);
+/* test hook: the R-/O-Net launches are sized by optimistic per-frame candidate capacities; set them (<= 0 keeps a value) and read
+ * how many attempts the last call took (a too-small capacity makes the call re-run itself with a larger one) */
+int  trl_debug_batch_capacity(trl_ctx* ctx, float t2_per_frame, float t3_per_frame, int* last_attempts);
 /* test hook: level `level` of one frame's image pyramid as the fused PNet kernel reads it; d_out holds h*w*3 floats
  * (capacity: at least (int(H*m+1))*(int(W*m+1))*3 with m = 12/min_face_size) */
 int  trl_debug_pyramid_level(trl_ctx* ctx, const uint8_t* d_frame, int H, int W, int level, float* d_out, int* h, int* w, void* stream);

@@ -308,3 +308,27 @@ def test_cascade_stress_inputs(blob, oracle, kind):
                        np.concatenate([np.full((60, 160, 3), 255, np.uint8), np.zeros((60, 160, 3), np.uint8)])])
     eng = Engine(blob, cap_level=3072, cap_frame=3072)
     _check_cascade(eng, oracle, fr)
+
+
+def test_batch_capacity_overflow_reruns_the_call(blob, oracle):
+    """The R-/O-Net launches are sized by an optimistic capacity kept on the host while the real candidate totals stay on the
+    device (no mid-call synchronisation).  When a total exceeds its capacity the call must notice and re-run itself with a larger
+    one -- never return results computed from a truncated batch."""
+    from truely_amd.engine import Engine
+    eng = Engine(blob)
+    fr = truely_amd.synthetic.synthetic_frames(4, 360, 640, seed=11)
+    ref = oracle.detect_embed(fr)
+    eng.batch_capacity(0.25, 0.25)                       # one candidate of head-room for four frames: both stages overflow
+    out = eng.detect_embed(fr)
+    assert eng.batch_capacity() >= 2                     # the call needed more than one attempt ...
+    for k in ("box", "prob", "rect", "valid", "emb"):    # ... and still returned the full result
+        assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+    out2 = eng.detect_embed(fr)
+    assert eng.batch_capacity() == 1                     # capacities were raised: the next call fits at once
+    assert np.array_equal(out2["emb"].cpu().numpy(), ref["emb"])
+    eng.batch_capacity(0.25, 1000.0)                     # only the R-Net batch overflows
+    b, p, c = eng.mtcnn_detect(fr)
+    assert eng.batch_capacity() >= 2
+    rb, rp = oracle.detect(fr[0])
+    k0 = int(c[0])
+    assert (rb is None and k0 == 0) or np.array_equal(b[0, :k0].cpu().numpy(), rb)

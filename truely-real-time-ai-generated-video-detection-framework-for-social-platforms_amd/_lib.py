@@ -41,6 +41,7 @@ _SIGNATURES = {
     "trl_debug_stage_boxes": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "trl_debug_level_counts": (C.c_int, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
     "trl_debug_level_cands": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
+    "trl_debug_batch_capacity": (C.c_int, [_vp, _f, _f, C.POINTER(_i)]),
     "trl_debug_poison": (C.c_int, [_vp, _i]),
     "trl_debug_pyramid_level": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),
     "trl_debug_pnet_level": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),

@@ -338,6 +338,7 @@ static int mtcnn_detect_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, 
         TRL_HIP(hipStreamSynchronize(s));             // the call's one host synchronisation
         int retry = 0;
         TRL_CHECK(trl_cascade_check(c, n, &retry));
+        c->last_attempts = attempt + 1;
         if (!retry) break;
         if (attempt >= 3) { trl_set_error("candidate batch capacity did not converge"); return TRL_ERR_STATE; }
     }
@@ -376,6 +377,7 @@ int trl_detect_embed(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, f
         TRL_HIP(hipStreamSynchronize(s));             // the call's one host synchronisation
         int retry = 0;
         TRL_CHECK(trl_cascade_check(c, n, &retry));
+        c->last_attempts = attempt + 1;
         if (!retry) break;                            // (a retry re-runs the call with larger R-/O-Net batch capacities)
         if (attempt >= 3) { trl_set_error("candidate batch capacity did not converge"); return TRL_ERR_STATE; }
     }
@@ -508,6 +510,16 @@ int trl_debug_crop_resize(trl_ctx* c, const uint8_t* d_frames, int n, int H, int
     if (!c || !d_frames || !d_rect || !d_valid || !d_faces || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
     return trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, d_faces, (hipStream_t)stream);
 }
+// test hook: set the optimistic R-/O-Net batch capacities (candidates per frame) the next call starts from, and read back how
+// many attempts the last call needed (> 1: a capacity was too small and the call was re-run with a larger one)
+int trl_debug_batch_capacity(trl_ctx* c, float t2_per_frame, float t3_per_frame, int* last_attempts) {
+    if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
+    if (t2_per_frame > 0.f) c->t2_per_frame = t2_per_frame;
+    if (t3_per_frame > 0.f) c->t3_per_frame = t3_per_frame;
+    if (last_attempts) *last_attempts = c->last_attempts;
+    return TRL_OK;
+}
+
 int trl_debug_pnet_kernel_ms(trl_ctx* c, float* ms) {
     if (!c || !ms) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
     *ms = c->pnet_kernel_ms;

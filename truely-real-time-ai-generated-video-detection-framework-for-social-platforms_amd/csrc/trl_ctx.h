@@ -57,6 +57,7 @@ struct trl_ctx {
     // exit early on the device; a call that overflows one is re-run with a larger value (trl_cascade.hip)
     float t2_per_frame = 160.f, t3_per_frame = 48.f;
     int cap_t2 = 0, cap_t3 = 0;      // capacities of the call in progress
+    int last_attempts = 0;           // attempts the last call took (test hook)
     size_t scratch_after_cascade = 0;   // scratch bytes the rest of the call needs (crops + FaceNet): sized with the cascade's
     int rnet_front_mode = -1, onet_front_mode = -1;   // conv1 PReLU slope class (trl_front.hip), -1 = not yet classified
     uint32_t* pyr_tab = nullptr;     // pyramid bin-edge tables for the last (H, W)

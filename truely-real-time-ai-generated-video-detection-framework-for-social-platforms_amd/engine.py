@@ -158,6 +158,12 @@ class Engine:
         _lib.check(self.lib.trl_debug_pyramid_level(self._h, _ptr(fr), H, W, int(level), _ptr(out), C.byref(h), C.byref(w), self._stream()))
         return out[:h.value * w.value * 3].view(h.value, w.value, 3)
 
+    def batch_capacity(self, t2_per_frame: float = 0.0, t3_per_frame: float = 0.0) -> int:
+        """Test hook: set the optimistic R-/O-Net candidate capacities (per frame) and return the attempts the last call took."""
+        k = C.c_int()
+        _lib.check(self.lib.trl_debug_batch_capacity(self._h, float(t2_per_frame), float(t3_per_frame), C.byref(k)))
+        return k.value
+
     def poison_workspaces(self, byte: int = 0xFF):
         """Test hook: fill the activation workspaces with a byte pattern (0xFF = NaNs)."""
         _lib.check(self.lib.trl_debug_poison(self._h, int(byte)))
