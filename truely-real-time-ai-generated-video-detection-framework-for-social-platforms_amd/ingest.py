@@ -48,7 +48,46 @@ class Nv12Uploader:
         self.pinned = [torch.empty((max_frames, fb), dtype=torch.uint8).pin_memory() for _ in range(slots)]
         self.dev_nv12 = [torch.empty((max_frames, fb), dtype=torch.uint8, device=engine.device) for _ in range(slots)]
         self.done = [None] * slots          # event: the H2D copy out of pinned[i] has finished
+        self.free = [None] * slots          # event: the conversion kernel that read dev_nv12[i] has finished
+        self.count = [0] * slots
+        self.copy_stream = None
         self.i = 0
+
+    def prefetch(self, nv12_host) -> int:
+        """Start the host -> device copy of the NEXT batch on the uploader's own copy stream and return its slot; the copy runs
+        while the engine's stream is busy with the current batch (PCIe and kernels overlap).  ``convert(slot, step)`` then makes
+        the engine's stream wait for the copy and converts."""
+        n = int(nv12_host.shape[0])
+        if n > self.max_frames:
+            raise ValueError(f"batch of {n} frames exceeds the uploader's {self.max_frames}")
+        i = self.i
+        self.i = (i + 1) % len(self.pinned)
+        src = nv12_host if isinstance(nv12_host, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(nv12_host))
+        if self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream(self.eng.device)
+        if self.free[i] is not None:
+            self.copy_stream.wait_event(self.free[i])      # the conversion that last read this device buffer has finished
+        if not src.is_pinned():
+            if self.done[i] is not None:
+                self.done[i].synchronize()
+            self.pinned[i][:n].copy_(src)
+            src = self.pinned[i][:n]
+        with torch.cuda.stream(self.copy_stream):
+            self.dev_nv12[i][:n].copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.done[i] = ev
+        self.count[i] = n
+        return i
+
+    def convert(self, slot: int, step: int = 1) -> torch.Tensor:
+        stream = torch.cuda.current_stream(self.eng.device)
+        stream.wait_event(self.done[slot])
+        out = self.eng.ingest_nv12(self.dev_nv12[slot][:self.count[slot]], self.H, self.W, step)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.free[slot] = ev
+        return out
 
     def upload(self, nv12_host, step: int = 1) -> torch.Tensor:
         n = int(nv12_host.shape[0])
