@@ -3,6 +3,7 @@ sharding helpers, and model.run's error convention (server/model.py:20-34).  No 
 import ctypes
 import os
 import re
+import struct
 
 import numpy as np
 import pytest
@@ -245,3 +246,60 @@ def test_nv12_container_roundtrip(tmp_path):
     gray = np.full((1, 4, 4, 3), 128, np.uint8)                        # BT.601 limited range: mid grey -> Y = 126, U = V = 128
     g = bgr_to_nv12(gray)[0]
     assert (g[:16] == 126).all() and (g[16:] == 128).all()
+
+
+def _box(typ, payload):
+    return struct.pack(">I4s", 8 + len(payload), typ) + payload
+
+
+def test_mp4_probe_plain_file(tmp_path):
+    """A minimal non-fragmented ISO-BMFF file built here: size, timescale -> fps, sample table -> frame count and byte ranges."""
+    import struct as st
+    from truely_amd import mp4probe
+    sps, pps = bytes([0x67, 100, 0, 31, 0xAC]), bytes([0x68, 0xEE, 0x3C, 0x80])
+    avcc = _box(b"avcC", bytes([1, 100, 0, 31, 0xFF, 0xE1]) + st.pack(">H", len(sps)) + sps + bytes([1]) + st.pack(">H", len(pps)) + pps)
+    entry_body = bytes(6) + st.pack(">H", 1) + bytes(16) + st.pack(">HH", 320, 180) + bytes(50) + avcc
+    stsd = _box(b"stsd", st.pack(">II", 0, 1) + st.pack(">I4s", 8 + len(entry_body), b"avc1") + entry_body)
+    sizes = [100, 40, 60, 30, 50]
+    stts = _box(b"stts", st.pack(">III", 0, 1, 5) + st.pack(">I", 512))
+    stsc = _box(b"stsc", st.pack(">II", 0, 1) + st.pack(">III", 1, 5, 1))
+    stsz = _box(b"stsz", st.pack(">III", 0, 0, 5) + st.pack(">5I", *sizes))
+    stco = _box(b"stco", st.pack(">II", 0, 1) + st.pack(">I", 4096))
+    stbl = _box(b"stbl", stsd + stts + stsc + stsz + stco)
+    hdlr = _box(b"hdlr", st.pack(">II4s", 0, 0, b"vide") + bytes(13))
+    mdhd = _box(b"mdhd", st.pack(">IIIII", 0, 0, 0, 12800, 2560) + bytes(4))
+    mdia = _box(b"mdia", mdhd + hdlr + _box(b"minf", stbl))
+    tkhd = _box(b"tkhd", st.pack(">IIII", 0, 0, 0, 7) + bytes(68))
+    moov = _box(b"moov", _box(b"trak", tkhd + mdia))
+    path = tmp_path / "clip.mp4"
+    path.write_bytes(_box(b"ftyp", b"isom" + bytes(4)) + moov)
+    i = mp4probe.probe(str(path))
+    assert (i.width, i.height, i.frame_count, i.codec, i.profile_idc, i.nal_length_size) == (320, 180, 5, "avc1", 100, 4)
+    assert abs(i.fps - 25.0) < 1e-9 and i.sps == [sps] and i.pps == [pps] and not i.fragmented
+    assert i.sample_ranges == [(4096, 100), (4196, 40), (4236, 60), (4296, 30), (4326, 50)]
+    assert "H.264 High@L3.1 320x180, 25.000 fps, 5 frames" in video_io.describe(str(path))
+    assert mp4probe.probe(__file__) is None and video_io.describe(__file__) == "unknown container"
+
+
+def test_mp4_probe_reference_sample():
+    """The reference's own sample clip (BASELINE configs[0]; fragmented mp4 from yt-dlp): the container facts SURVEY section 6
+    lists -- 640x360, 30 fps, 960 frames -- read by this build's demultiplexer.  (Decoding it needs OpenCV: DESIGN section 8.)"""
+    import glob
+    from truely_amd import mp4probe
+    files = glob.glob("/root/reference/test/*.mp4")
+    if not files:
+        pytest.skip("the reference checkout is not present on this box")
+    i = mp4probe.probe(files[0])
+    assert (i.width, i.height, i.frame_count, i.fragmented, i.codec) == (640, 360, 960, True, "avc1")
+    assert abs(i.fps - 30.0) < 1e-9 and i.profile_idc == 77 and len(i.sps) == 1 and len(i.pps) == 1
+    n, idr = 0, 0
+    for au in mp4probe.samples(files[0], i):
+        q = 0
+        while q + 4 <= len(au):
+            ln = int.from_bytes(au[q:q + 4], "big")
+            idr += (au[q + 4] & 31) == 5
+            q += 4 + ln
+        assert q == len(au)                                   # every access unit is a whole number of NAL units
+        n += 1
+    assert n == 960 and idr >= 1
+    assert max(1, int(int(i.fps) / 7)) == 4                   # model.py:40 -> 240 sampled frames (SURVEY 8c)

@@ -69,6 +69,7 @@ def run(video_path_one: str, video_path_two: str) -> int:
     opened = video_io.open_reader(video_path_one)
     if opened is None:   # model.py:24-26
         print(f"Error: OpenCV couldn't open video file {video_path_one}")
+        print(f"       ({video_io.describe(video_path_one)})")
         return 0
     cap, fps, width, height = opened
     if width <= 0 or height <= 0 or fps <= 0:   # model.py:30-33

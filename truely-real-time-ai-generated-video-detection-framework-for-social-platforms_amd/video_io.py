@@ -145,6 +145,20 @@ def open_reader(path):
     return None
 
 
+def describe(path) -> str:
+    """One line about a clip this build cannot decode (no OpenCV): what the container says it is."""
+    from . import mp4probe
+    try:
+        i = mp4probe.probe(path)
+    except Exception:  # noqa: BLE001 - a damaged container is simply "unknown"
+        i = None
+    if i is None:
+        return "unknown container"
+    prof = {66: "Baseline", 77: "Main", 88: "Extended", 100: "High"}.get(i.profile_idc, str(i.profile_idc))
+    return (f"H.264 {prof}@L{i.level_idc / 10:.1f} {i.width}x{i.height}, {i.fps:.3f} fps, {i.frame_count} frames"
+            f"{' (fragmented mp4)' if i.fragmented else ''}: decoding needs opencv-python (cv2.VideoCapture), or hand run() decoder output as an NV12 TRLV clip")
+
+
 def open_writer(path, fps, size, like_raw: bool):
     if cv2 is not None and not like_raw:  # pragma: no cover
         return cv2.VideoWriter(path, cv2.VideoWriter_fourcc(*"H264"), fps, size)
