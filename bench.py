@@ -123,6 +123,9 @@ def parse_args(argv=None):
     ap.add_argument("--in-flight", type=int, default=2,
                     help="batches in flight per GPU: each gets its own context, HIP stream and host thread; 1 = strictly sequential")
     ap.add_argument("--master-port", type=int, default=None)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the per-step collective even with ONE rank: exercises the RCCL branch "
+                         "(init, all-gather of the result rows, barrier, all-reduce of the time) on a single-GPU box")
     return ap.parse_args(argv)
 
 
@@ -166,7 +169,12 @@ def main():
         sys.exit(f"bench.py: {world} RCCL ranks need {world} GPUs, found {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port or (29500 + os.getpid() % 3000)))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -221,7 +229,7 @@ def main():
 
     def finish(out):
         """Main thread, step order on every rank: the one collective of the path (sharded mode), then the drift state machine."""
-        if world > 1 and sharded:
+        if use_dist and sharded:
             emb, valid = allgather_embeddings(out["emb"], out["valid"], counts=counts)
         else:
             emb, valid = out["emb"], out["valid"]
@@ -272,7 +280,7 @@ def main():
         return last, acc
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -284,7 +292,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     pnet_ms, pyr_ms, pnet_kernel_ms = acc["pnet_ms"], acc["pyramid_ms"], acc["pnet_kernel_ms"]
-    if world > 1:
+    if use_dist:
         tdev = dev if args.backend == "nccl" else torch.device("cpu")
         tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -327,7 +335,7 @@ def main():
                        "valid_faces": int(out["valid"].sum().item()), "score": d["score"], "scores": scores,
                        "emb_crc32": zlib.crc32(emb_all.tobytes()), "mode": args.mode, "ingest": args.ingest,
                        "pnet_path": "fused" if eng.cfg.pnet_mode == 0 else "generic layers",
-                       "parallelism": par, "backend": args.backend if world > 1 else None, "batches_in_flight": F},
+                       "parallelism": par, "backend": args.backend if use_dist else None, "batches_in_flight": F},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "kernel": "k_pnet_fused (PNet over the pyramid: 83% of the conv FLOPs at 720p)",
@@ -342,7 +350,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

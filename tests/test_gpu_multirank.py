@@ -60,3 +60,16 @@ def test_rccl_needs_as_many_gpus_as_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
                        timeout=120, cwd=ROOT)
     assert p.returncode != 0 and "needs 2 visible GPUs" in p.stderr
+
+
+def test_rccl_branch_single_rank(engine):
+    """The RCCL code path itself -- `init_process_group("nccl", device_id=...)`, the all-gather of the result rows, barrier, the
+    all-reduce of the step time -- executed for real on this one-GPU box with a world of ONE rank (RCCL refuses two ranks on one
+    device, so N > 1 over RCCL is the 8-GPU node's to run).  Same result as the plain single-GPU run."""
+    n = 6
+    r = _bench("--gpus", "1", "--force-dist", "--backend", "nccl", "--batch", str(n), "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert r["n_gpus"] == 1 and r["config"]["backend"] == "nccl"
+    fr = truely_amd.synthetic.synthetic_frames(n, 720, 1280, seed=0)
+    out = engine.detect_embed(fr)
+    assert r["config"]["emb_crc32"] == zlib.crc32(out["emb"].cpu().numpy().tobytes())
+    assert r["config"]["score"] == engine.drift_score(out["emb"], out["valid"], n * 4, 30)["score"]
