@@ -38,9 +38,9 @@ CONFIGS = {
     2: dict(H=1080, W=1920, batch=128, faces=-1, min_face=20, embed="bf16", dtype="f32+bf16", unique=16,
             name="BASELINE configs[2]: synthetic 1080p multi-face (3-5 faces/frame) stream, batch=128 per GPU, f32 detector "
                  "(bit-exact cascade) + bf16-MFMA InceptionResnetV1 embedder, largest face embedded (server/model.py:49)"),
-    4: dict(H=2160, W=3840, batch=32, faces=1, min_face=40, embed="f32", dtype="f32", unique=4,
-            name="BASELINE configs[4]: synthetic 4K frames, MTCNN pyramid 12 scales (min_face_size=40), batch=32 per GPU, "
-                 "f32 (an fp16 detector cannot keep box/NMS parity: not built, DESIGN.md section 8)"),
+    4: dict(H=2160, W=3840, batch=32, faces=1, min_face=40, embed="fp16", dtype="f32+fp16", unique=4,
+            name="BASELINE configs[4]: synthetic 4K frames, MTCNN pyramid 12 scales (min_face_size=40), batch=32 per GPU, f32 detector "
+                 "(an fp16 detector cannot keep box/NMS parity: not built, DESIGN.md section 8) + fp16-MFMA InceptionResnetV1 embedder"),
 }
 
 

@@ -59,7 +59,8 @@ typedef struct {
     int    embed_precision; /* 0 = f32, bit-exact with the oracle                                        [default]
                              * 1 = bf16 activations/weights on the bf16 matrix cores for InceptionResnetV1 only
                              *     (BASELINE configs[2]); detector, crops and valid mask stay f32-exact; embeddings
-                             *     agree with the f32 path to ~1e-2 (cosine > 0.999), see tests/test_gpu_api.py */
+                             *     agree with the f32 path to ~1e-2 (cosine > 0.999), see tests/test_gpu_api.py
+                             * 2 = the same on fp16 (BASELINE configs[4]): three more mantissa bits, cosine > 0.99999 */
 } trl_config;
 
 int  trl_abi_version(void);

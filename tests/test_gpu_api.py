@@ -176,6 +176,35 @@ def test_bf16_embedder_mode(blob, oracle):
     assert np.abs(sims - sref).max() <= 5e-2
 
 
+def test_fp16_embedder_mode(blob, oracle):
+    """trl_config.embed_precision = 2 (BASELINE configs[4], 'fp16'): the same reduced-precision embedder on
+    v_mfma_f32_32x32x16_f16.  Three more mantissa bits than bf16, so the stated tolerance is tighter: cosine >= 0.99999 and
+    max |diff| <= 3e-3 on unit vectors for random inputs, cosine >= 0.9999 on detected faces, drift similarities within 5e-3.
+    Decisions (boxes, rects, valid mask) are the f32 path's, bit for bit.  No value overflows fp16's range (all finite)."""
+    from truely_amd.engine import Engine
+    eng = Engine(blob, embed_precision="fp16")
+    rng = np.random.default_rng(9)
+    x = rng.uniform(0, 1, (6, 80, 80, 3)).astype(np.float32)
+    ref = oracle.facenet(x)
+    got = eng.facenet_embed(torch.from_numpy(x)).cpu().numpy()
+    cos = (got * ref).sum(1)
+    assert np.all(np.isfinite(got)) and np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    assert cos.min() >= 0.99999, cos
+    assert np.abs(got - ref).max() <= 3e-3, np.abs(got - ref).max()
+    bf = Engine(blob, embed_precision="bf16").facenet_embed(torch.from_numpy(x)).cpu().numpy()
+    assert np.abs(got - ref).max() < np.abs(bf - ref).max()          # and it IS closer than bf16
+    fr = truely_amd.synthetic.synthetic_frames(6, 360, 640, seed=11)
+    out, exp = eng.detect_embed(fr), oracle.detect_embed(fr)
+    for k in ("box", "prob", "rect", "valid"):
+        assert np.array_equal(out[k].cpu().numpy(), exp[k]), k
+    v = exp["valid"].astype(bool)
+    e = out["emb"].cpu().numpy()
+    assert ((e[v] * exp["emb"][v]).sum(1)).min() >= 0.9999
+    d = eng.drift_score(out["emb"], out["valid"], len(fr) * 4, 30)
+    dref = oracle.drift_score(exp["emb"], exp["valid"], len(fr) * 4, 30)
+    assert np.abs(d["sims"].cpu().numpy() - np.asarray(dref["sims"])).max() <= 5e-3
+
+
 def test_two_contexts_on_two_threads(blob):
     """bench.py keeps two batches in flight: two contexts, two HIP streams, two host threads.  Results must be the
     bits a single context produces (no shared mutable state in the library besides per-context workspaces)."""

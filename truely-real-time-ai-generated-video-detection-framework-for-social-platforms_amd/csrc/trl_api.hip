@@ -39,7 +39,7 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
     if (!cfg || !out) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
     if (cfg->cap_level < 64 || cfg->cap_level > 3072 || cfg->cap_frame < 64 || cfg->cap_frame > 3072 || (cfg->cap_level & 3) ||
         (cfg->cap_frame & 3) || cfg->min_face_size < 12 || cfg->max_faces < 1 || !(cfg->factor > 0.1 && cfg->factor < 0.99) || cfg->embed_mode < 0 || cfg->embed_mode > 2 ||
-        cfg->embed_precision < 0 || cfg->embed_precision > 1) {
+        cfg->embed_precision < 0 || cfg->embed_precision > 2) {
         trl_set_error("bad trl_config (capacities must be multiples of 4 in [64,3072], min_face_size >= 12)");
         return TRL_ERR_INVALID;
     }
@@ -253,11 +253,11 @@ extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
 
     TRL_CHECK(trl_pnet_prepare(c));
     c->rnet_front_mode = c->onet_front_mode = -1;
-    if (c->cfg.embed_precision == 1) {   // bf16 copies of the embedder's conv weights (all but the 3-channel stem and the final linear)
+    if (c->cfg.embed_precision >= 1) {   // bf16 / fp16 copies of the embedder's conv weights (all but the 3-channel stem and the final linear)
         for (auto& kv : c->W) {
             const std::string& nm = kv.first;
             if (nm.rfind("facenet.", 0) != 0 || nm == "facenet.conv2d_1a.w" || nm == "facenet.last_linear.w") continue;
-            TRL_CHECK(trl_make_weight_bf16(&kv.second, nullptr));
+            TRL_CHECK(trl_make_weight_bf16(&kv.second, nullptr, c->cfg.embed_precision));
         }
         TRL_HIP(hipDeviceSynchronize());
     }

@@ -1,4 +1,5 @@
-// trl_bf16.hip -- optional reduced-precision embedder (trl_config.embed_precision = 1; BASELINE configs[2] "bf16 MFMA").
+// trl_bf16.hip -- optional reduced-precision embedder: trl_config.embed_precision = 1 (bf16, BASELINE configs[2] "bf16 MFMA")
+// or 2 (fp16, BASELINE configs[4] "fp16"); every kernel is a template on the 16-bit format P.
 //
 // InceptionResnetV1 with bf16 activations + bf16 weights on v_mfma_f32_32x32x16_bf16 (f32 accumulate), folded BN /
 // residual / ReLU epilogue in f32, one rounding to bf16 per stored activation.  NOT the parity path: the default
@@ -12,6 +13,7 @@
 #include "trl_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -23,7 +25,18 @@ __device__ __forceinline__ uint16_t f2bf(float f) {            // round to neare
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-template <int BM, int BN, int BK, bool PAD>
+// P = 1: bf16 (8 exponent bits: no range concerns), P = 2: IEEE fp16 (3 more mantissa bits; FaceNet's activations are O(1..100),
+// far inside +-65504, and a value that did overflow would surface as inf -> NaN embedding, never as a silent wrong number)
+template <int P> __device__ __forceinline__ float lp2f(uint16_t h) {
+    if (P == 1) return bf2f(h);
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+template <int P> __device__ __forceinline__ uint16_t f2lp(float f) {
+    if (P == 1) return f2bf(f);
+    return __builtin_bit_cast(uint16_t, (_Float16)f);       // v_cvt_f16_f32: round to nearest even
+}
+
+template <int BM, int BN, int BK, bool PAD, int P>
 __global__ __launch_bounds__(256) void conv_bf16(ConvArgs a) {
     constexpr int LDS_K = BK + 8;                                // bf16 elements per staged row (16-byte pad)
     constexpr int KG = BK / 8;                                   // 16-byte groups along k per chunk
@@ -118,18 +131,20 @@ __global__ __launch_bounds__(256) void conv_bf16(ConvArgs a) {
         if (ch + 1 < nchunks) load_chunk();
 #pragma unroll
         for (int kk = 0; kk < BK / 16; kk++) {
-            bf16x8 av[TM], bv[TN];
+            u32x4 av[TM], bv[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; tm++)
-                av[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&As[((wm * TM + tm) * 32 + r) * LDS_K + 16 * kk + 8 * h]));
+                av[tm] = *reinterpret_cast<const u32x4*>(&As[((wm * TM + tm) * 32 + r) * LDS_K + 16 * kk + 8 * h]);
 #pragma unroll
             for (int tn = 0; tn < TN; tn++)
-                bv[tn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Bs[((wn * TN + tn) * 32 + r) * LDS_K + 16 * kk + 8 * h]));
+                bv[tn] = *reinterpret_cast<const u32x4*>(&Bs[((wn * TN + tn) * 32 + r) * LDS_K + 16 * kk + 8 * h]);
 #pragma unroll
             for (int tm = 0; tm < TM; tm++)
 #pragma unroll
-                for (int tn = 0; tn < TN; tn++)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+                for (int tn = 0; tn < TN; tn++) {
+                    if (P == 1) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[tm]), __builtin_bit_cast(bf16x8, bv[tn]), acc[tm][tn], 0, 0, 0);
+                    else acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[tm]), __builtin_bit_cast(f16x8, bv[tn]), acc[tm][tn], 0, 0, 0);
+                }
         }
         __syncthreads();
     }
@@ -148,29 +163,32 @@ __global__ __launch_bounds__(256) void conv_bf16(ConvArgs a) {
                 if (mr >= a.M) continue;
                 float v = acc[tm][tn][i];
                 if (a.scale) v = __builtin_fmaf(v, sc, sf);
-                if (a.res) v = v * a.res_scale + bf2f(rg[(size_t)mr * a.ldres + n]);
+                if (a.res) v = v * a.res_scale + lp2f<P>(rg[(size_t)mr * a.ldres + n]);
                 if (a.act == TRL_ACT_RELU) v = v > 0.f ? v : 0.f;
-                yg[(size_t)mr * a.ldy + a.yoff + n] = f2bf(v);
+                yg[(size_t)mr * a.ldy + a.yoff + n] = f2lp<P>(v);
             }
         }
     }
 }
 
-// f32 NHWC -> bf16 (same shape, dense)
+// f32 NHWC -> 16-bit (same shape, dense)
+template <int P>
 __global__ void k_to_bf16(const float* __restrict__ x, size_t n, uint16_t* __restrict__ y) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = f2lp<P>(x[i]);
 }
 
 // [K][ld] f32 (HWIO rows) -> bf16 transposed [Cp][Kp], zero padded
+template <int P>
 __global__ void k_weight_bf16_t(const float* __restrict__ w, int K, int ld, int Cout, uint16_t* __restrict__ wt, int Kp, int Cp) {
     const size_t total = (size_t)Cp * Kp;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / Kp), k = (int)(i - (size_t)n * Kp);
-        wt[i] = (n < Cout && k < K) ? f2bf(w[(size_t)k * ld + n]) : (uint16_t)0;
+        wt[i] = (n < Cout && k < K) ? f2lp<P>(w[(size_t)k * ld + n]) : (uint16_t)0;
     }
 }
 
-// max pool k x k / stride st (no padding, floor mode) on bf16 NHWC views, 8 channels per thread
+// max pool k x k / stride st (no padding, floor mode) on 16-bit NHWC views, 8 channels per thread
+template <int P>
 __global__ void k_maxpool_bf16(const uint16_t* __restrict__ x, int N, int H, int W, int C, int ldx, int xoff, int k, int st,
                                uint16_t* __restrict__ y, int ldy, int yoff, int OH, int OW) {
     const int C8 = C / 8;
@@ -191,34 +209,38 @@ __global__ void k_maxpool_bf16(const uint16_t* __restrict__ x, int N, int H, int
                 const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)(n * H + iy) * W + ix) * ldx + xoff + 8 * c8);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float lo = __builtin_bit_cast(float, v[j] << 16), hi = __builtin_bit_cast(float, v[j] & 0xFFFF0000u);
+                    const float lo = lp2f<P>((uint16_t)(v[j] & 0xFFFFu)), hi = lp2f<P>((uint16_t)(v[j] >> 16));
                     best[2 * j] = lo > best[2 * j] ? lo : best[2 * j];
                     best[2 * j + 1] = hi > best[2 * j + 1] ? hi : best[2 * j + 1];
                 }
             }
         u32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            o[j] = (__builtin_bit_cast(unsigned, best[2 * j]) >> 16) | (__builtin_bit_cast(unsigned, best[2 * j + 1]) & 0xFFFF0000u);
+        for (int j = 0; j < 4; j++) o[j] = (unsigned)f2lp<P>(best[2 * j]) | ((unsigned)f2lp<P>(best[2 * j + 1]) << 16);   // exact: the values ARE 16-bit
         *reinterpret_cast<u32x4*>(y + ((size_t)(n * OH + oy) * OW + ox) * ldy + yoff + 8 * c8) = o;
     }
 }
 
 // global average pool of a bf16 map -> f32 [N][C] (sum in pixel order, then / HW: the f32 kernel's expression)
+template <int P>
 __global__ void k_gap_bf16(const uint16_t* __restrict__ x, int N, int HW, int C, float* __restrict__ y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C;
     float s = 0.f;
-    for (int p = 0; p < HW; p++) s += bf2f(x[((size_t)n * HW + p) * C + c]);
+    for (int p = 0; p < HW; p++) s += lp2f<P>(x[((size_t)n * HW + p) * C + c]);
     y[i] = s / (float)HW;
 }
 
 template <int BM, int BN, int BK>
 int launch_bf16(const ConvArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
-    if (a.ph || a.pw) conv_bf16<BM, BN, BK, true><<<grid, 256, 0, s>>>(a);
-    else conv_bf16<BM, BN, BK, false><<<grid, 256, 0, s>>>(a);
+    const bool pad = a.ph || a.pw;
+    if (a.lowp == 2) {
+        if (pad) conv_bf16<BM, BN, BK, true, 2><<<grid, 256, 0, s>>>(a); else conv_bf16<BM, BN, BK, false, 2><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (pad) conv_bf16<BM, BN, BK, true, 1><<<grid, 256, 0, s>>>(a); else conv_bf16<BM, BN, BK, false, 1><<<grid, 256, 0, s>>>(a);
+    }
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
@@ -237,42 +259,44 @@ int trl_launch_conv_bf16(const ConvArgs& a, hipStream_t s) {
     return k32 ? launch_bf16<64, 64, 32>(a, s) : launch_bf16<64, 64, 16>(a, s);
 }
 
-int trl_launch_to_bf16(const float* x, size_t n, uint16_t* y, hipStream_t s) {
+int trl_launch_to_bf16(const float* x, size_t n, uint16_t* y, hipStream_t s, int fmt) {
     if (n == 0) return TRL_OK;
     size_t blocks = (n + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    k_to_bf16<<<(unsigned)blocks, 256, 0, s>>>(x, n, y);
+    if (fmt == 2) k_to_bf16<2><<<(unsigned)blocks, 256, 0, s>>>(x, n, y); else k_to_bf16<1><<<(unsigned)blocks, 256, 0, s>>>(x, n, y);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
 
-int trl_make_weight_bf16(DevW* w, hipStream_t s) {
+int trl_make_weight_bf16(DevW* w, hipStream_t s, int fmt) {
     if (w->pt) return TRL_OK;
     const int Kp = (w->K + 31) & ~31, Cp = (w->Cout + 63) & ~63;
     TRL_HIP(hipMalloc((void**)&w->pt, (size_t)Kp * Cp * sizeof(uint16_t) + 64));
     w->ldt = Kp;
     size_t blocks = ((size_t)Kp * Cp + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    k_weight_bf16_t<<<(unsigned)blocks, 256, 0, s>>>(w->p, w->K, w->ld, w->Cout, w->pt, Kp, Cp);
+    if (fmt == 2) k_weight_bf16_t<2><<<(unsigned)blocks, 256, 0, s>>>(w->p, w->K, w->ld, w->Cout, w->pt, Kp, Cp);
+    else k_weight_bf16_t<1><<<(unsigned)blocks, 256, 0, s>>>(w->p, w->K, w->ld, w->Cout, w->pt, Kp, Cp);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
 
 int trl_launch_maxpool_bf16(const uint16_t* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st, uint16_t* y, int ldy,
-                            int yoff, int OH, int OW, hipStream_t s) {
+                            int yoff, int OH, int OW, hipStream_t s, int fmt) {
     if ((C % 8) || (ldx % 8) || (xoff % 8) || (ldy % 8) || (yoff % 8)) { trl_set_error("bf16 max-pool needs channel counts in multiples of 8"); return TRL_ERR_INVALID; }
     const size_t total = (size_t)N * OH * OW * (C / 8);
     if (total == 0) return TRL_OK;
     size_t blocks = (total + 255) / 256;
     if (blocks > 32768) blocks = 32768;
-    k_maxpool_bf16<<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW);
+    if (fmt == 2) k_maxpool_bf16<2><<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW);
+    else k_maxpool_bf16<1><<<(unsigned)blocks, 256, 0, s>>>(x, N, H, W, C, ldx, xoff, k, st, y, ldy, yoff, OH, OW);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
 
-int trl_launch_gap_bf16(const uint16_t* x, int N, int HW, int C, float* y, hipStream_t s) {
+int trl_launch_gap_bf16(const uint16_t* x, int N, int HW, int C, float* y, hipStream_t s, int fmt) {
     if (N * C == 0) return TRL_OK;
-    k_gap_bf16<<<(N * C + 255) / 256, 256, 0, s>>>(x, N, HW, C, y);
+    if (fmt == 2) k_gap_bf16<2><<<(N * C + 255) / 256, 256, 0, s>>>(x, N, HW, C, y); else k_gap_bf16<1><<<(N * C + 255) / 256, 256, 0, s>>>(x, N, HW, C, y);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }

@@ -65,7 +65,7 @@ struct ConvArgs {
     // inside a live workgroup compute on in-bounds scratch and are never read).  No host round trip to size the grid.
     const int32_t* m_dev = nullptr; int m_base = 0; int m_per = 1;
     int ysplit = 1 << 30, yskip = 0;   // output column n >= ysplit is stored yskip channels further right (trl_fnconv.hip only)
-    int lowp = 0;                 // 1: x, y, res are bf16 and the weights come from wt (conv_bf16, FaceNet only)
+    int lowp = 0;                 // 1 / 2: x, y, res are bf16 / fp16 and the weights come from wt (conv_bf16, FaceNet only)
     const uint16_t* wt = nullptr; int ldwt = 0;
 };
 
@@ -102,11 +102,11 @@ int trl_launch_maxpool(const float* x, int N, int H, int W, int C, int ldx, int 
 int trl_launch_gap(const float* x, int N, int HW, int C, float* y, hipStream_t s);
 // reduced-precision embedder (trl_bf16.hip)
 int trl_launch_conv_bf16(const ConvArgs& a, hipStream_t s);
-int trl_launch_to_bf16(const float* x, size_t n, uint16_t* y, hipStream_t s);
-int trl_make_weight_bf16(DevW* w, hipStream_t s);
+int trl_launch_to_bf16(const float* x, size_t n, uint16_t* y, hipStream_t s, int fmt = 1);     // fmt: 1 = bf16, 2 = fp16
+int trl_make_weight_bf16(DevW* w, hipStream_t s, int fmt = 1);
 int trl_launch_maxpool_bf16(const uint16_t* x, int N, int H, int W, int C, int ldx, int xoff, int k, int st, uint16_t* y, int ldy,
-                            int yoff, int OH, int OW, hipStream_t s);
-int trl_launch_gap_bf16(const uint16_t* x, int N, int HW, int C, float* y, hipStream_t s);
+                            int yoff, int OH, int OW, hipStream_t s, int fmt = 1);
+int trl_launch_gap_bf16(const uint16_t* x, int N, int HW, int C, float* y, hipStream_t s, int fmt = 1);
 int trl_launch_l2norm512(const float* x, const uint8_t* valid, int n, float* y, hipStream_t s);
 int trl_launch_drift(const float* emb, const uint8_t* valid, int n, long long frame_count, int fps,
                      float* sims, uint8_t* flags, int32_t* result, hipStream_t s);

@@ -83,7 +83,7 @@ struct Runner {
                 err = TRL_ERR_STATE;
                 return y;
             }
-            a.lowp = 1; a.wt = w->pt; a.ldwt = w->ldt;
+            a.lowp = c->cfg.embed_precision; a.wt = w->pt; a.ldwt = w->ldt;
             if (res) a.res = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(res->p) + res->coff);
             int st = trl_launch_conv_bf16(a, s);
             if (st != TRL_OK) err = st;
@@ -115,7 +115,7 @@ struct Runner {
         if (err != TRL_OK) return y;
         if (x.bf) {
             int e = trl_launch_maxpool_bf16(reinterpret_cast<const uint16_t*>(x.p), x.n, x.h, x.w, x.c, x.ld, x.coff, k, st,
-                                            reinterpret_cast<uint16_t*>(y.p), y.ld, y.coff, OH, OW, s);
+                                            reinterpret_cast<uint16_t*>(y.p), y.ld, y.coff, OH, OW, s, c->cfg.embed_precision);
             if (e != TRL_OK) err = e;
             return y;
         }
@@ -180,10 +180,10 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
     Act x0; x0.p = const_cast<float*>(d_faces); x0.n = n; x0.h = h; x0.w = w; x0.c = 3; x0.ld = 3; x0.coff = 0;
     const std::string f = "facenet.";
     Act x = R.bconv(x0, f + "conv2d_1a", 3, 3, 2, 2, 0, 0);
-    if (c->cfg.embed_precision == 1) {   // everything after the 3-channel stem conv runs on bf16 activations (trl_bf16.hip)
+    if (c->cfg.embed_precision >= 1) {   // everything after the 3-channel stem conv runs on 16-bit activations (trl_bf16.hip)
         Act xb = R.alloc(x.n, x.h, x.w, x.c, true);
         if (R.err != TRL_OK) return R.err;
-        TRL_CHECK(trl_launch_to_bf16(x.p, x.pixels() * x.c, reinterpret_cast<uint16_t*>(xb.p), s));
+        TRL_CHECK(trl_launch_to_bf16(x.p, x.pixels() * x.c, reinterpret_cast<uint16_t*>(xb.p), s, c->cfg.embed_precision));
         x = xb;
     }
     x = R.bconv(x, f + "conv2d_2a", 3, 3, 1, 1, 0, 0);
@@ -236,7 +236,7 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
     } else {
         g = R.alloc(n, 1, 1, x.c);
         if (R.err != TRL_OK) return R.err;
-        if (x.bf) TRL_CHECK(trl_launch_gap_bf16(reinterpret_cast<const uint16_t*>(x.p), n, x.h * x.w, x.c, g.p, s));
+        if (x.bf) TRL_CHECK(trl_launch_gap_bf16(reinterpret_cast<const uint16_t*>(x.p), n, x.h * x.w, x.c, g.p, s, c->cfg.embed_precision));
         else TRL_CHECK(trl_launch_gap(x.p, n, x.h * x.w, x.c, g.p, s));
     }
     Act e = R.conv(g, trl_w(c, f + "last_linear.w"), nullptr, trl_v(c, f + "last_bn.scale"), trl_v(c, f + "last_bn.shift"),

@@ -37,7 +37,7 @@ class Engine:
         cfg.factor = float(factor)
         cfg.max_faces = int(max_faces)
         cfg.embed_mode = int(embed_mode)
-        cfg.embed_precision = {"f32": 0, "fp32": 0, "bf16": 1}.get(embed_precision, embed_precision) if isinstance(embed_precision, str) else int(embed_precision)
+        cfg.embed_precision = {"f32": 0, "fp32": 0, "bf16": 1, "fp16": 2, "f16": 2}.get(embed_precision, embed_precision) if isinstance(embed_precision, str) else int(embed_precision)
         if pnet_mode is not None:
             cfg.pnet_mode = int(pnet_mode)
         if cap_level:
