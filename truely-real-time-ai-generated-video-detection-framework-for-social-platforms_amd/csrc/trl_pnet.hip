@@ -1171,7 +1171,8 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     PnetArgs a;
     TRL_CHECK(build_pyramid(c, d_frames, n, H, W, a, ev, s));
     const int total_tiles = a.tiles_per_frame * n;
-    int grid = 256 * 2;                       // 2 resident workgroups per CU (<= 256 VGPRs)
+    static const int grid_env = getenv("TRL_PNET_GRID") ? atoi(getenv("TRL_PNET_GRID")) : 0;   // experiment: workgroups of the persistent launch
+    int grid = grid_env > 0 ? grid_env : 256 * 2;   // 2 resident workgroups per CU (<= 256 VGPRs)
     if (grid > ((total_tiles + 7) / 8) * 8) grid = ((total_tiles + 7) / 8) * 8;
     if (grid < 8) grid = 8;
     TRL_HIP(hipMemsetAsync(c->pnet_cursor, 0, 8 * sizeof(int32_t), s));
