@@ -443,9 +443,9 @@ __global__ __launch_bounds__(256) void conv_tap(ConvArgs a) {
     constexpr int KG = BK / 4;                                   // float4 groups along k per chunk
     constexpr int ASLOTS = BM * KG, APT = (ASLOTS + 255) / 256;
     constexpr int BSLOTS = BK * (BN / 4), BPT = (BSLOTS + 255) / 256;
-    constexpr int GSTEP = 256 / BM;                              // k-group stride between a thread's A slots
-    static_assert(WM * WN == 4 && 256 % BM == 0 && BK % 4 == 0 && BK % 2 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) float As[BK * BM];
+    constexpr int LDA = BK + 1;                                  // A tile [m][k], odd row stride: operand reads (lane = row) and the staging writes are conflict-free
+    static_assert(WM * WN == 4 && BK % 4 == 0 && BK % 2 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) float As[BM * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -454,16 +454,25 @@ __global__ __launch_bounds__(256) void conv_tap(ConvArgs a) {
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     if (m0 >= trl_live_rows(a)) return;     // device-sized batch: nothing of this tile exists (block-uniform)
 
-    // ---- per-thread A row: element offset of (image, iy0, ix0, channel 4*g0) from a.x ---------------------
-    const int row = tid % BM, g0 = tid / BM;
-    const int m = m0 + row;
-    const int mm = m < a.M ? m : 0;
+    // ---- A slots: slot = tid + 256 i -> (k-group = slot % KG, row = slot / KG).  The KG lanes of a row read the BK contiguous
+    // channels one pixel contributes to a chunk, so a wave's load touches 64 / KG pixels' lines instead of 64 (row-per-lane
+    // gathers spend the vector L1's request rate, not its bandwidth: round 2).  Element offset of
+    // (image, iy0, ix0, channel 4 g) from a.x; rows past M re-read row 0 (never stored).
     const int ohw = a.OH * a.OW;
-    const int nimg = mm / ohw;
-    const int rem = mm - nimg * ohw;
-    const int oy = rem / a.OW, ox = rem - oy * a.OW;
-    const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
-    const int aoff = ((nimg * a.H + iy0) * a.W + ix0) * a.ldx + a.xoff + 4 * g0;      // < 2^31: checked by the launcher
+    int aoff[APT], adst[APT], iy0v[APT], ix0v[APT];
+#pragma unroll
+    for (int i = 0; i < APT; i++) {
+        const int slot = tid + 256 * i;
+        const int g = slot % KG, row = slot / KG;
+        const int m = m0 + row;
+        const int mm = (m < a.M && row < BM) ? m : 0;
+        const int nimg = mm / ohw;
+        const int rem = mm - nimg * ohw;
+        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+        iy0v[i] = oy * a.sh - a.ph; ix0v[i] = ox * a.sw - a.pw;
+        aoff[i] = ((nimg * a.H + iy0v[i]) * a.W + ix0v[i]) * a.ldx + a.xoff + 4 * g;      // < 2^31: checked by the launcher
+        adst[i] = row * LDA + 4 * g;
+    }
     // ---- per-thread B slot: (k row kk0, column n) ------------------------------------------------------------
     const int bkk = tid / (BN / 4), bn4 = tid % (BN / 4);
     int bn = n0 + 4 * bn4;
@@ -477,13 +486,12 @@ __global__ __launch_bounds__(256) void conv_tap(ConvArgs a) {
     int k0 = 0;
     auto load_chunk = [&]() {
         const int soff = (ky * a.W + kx) * a.ldx + c0;         // scalar
-        bool inside = true;
-        if (PAD) inside = (unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W;
 #pragma unroll
         for (int i = 0; i < APT; i++) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((ASLOTS % 256 == 0 || tid + i * 256 < ASLOTS) && inside)
-                v = *reinterpret_cast<const float4*>(a.x + (aoff + soff + 4 * GSTEP * i));
+            bool ok = ASLOTS % 256 == 0 || tid + i * 256 < ASLOTS;
+            if (PAD) ok = ok && (unsigned)(iy0v[i] + ky) < (unsigned)a.H && (unsigned)(ix0v[i] + kx) < (unsigned)a.W;
+            if (ok) v = *reinterpret_cast<const float4*>(a.x + (aoff[i] + soff));
             areg[i] = v;
         }
         const float* wrow = a.w + (size_t)k0 * a.ldw;           // scalar
@@ -501,11 +509,8 @@ __global__ __launch_bounds__(256) void conv_tap(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < APT; i++) {
             if (ASLOTS % 256 == 0 || tid + i * 256 < ASLOTS) {
-                const int g = g0 + GSTEP * i;
-                As[(4 * g + 0) * BM + row] = areg[i].x;
-                As[(4 * g + 1) * BM + row] = areg[i].y;
-                As[(4 * g + 2) * BM + row] = areg[i].z;
-                As[(4 * g + 3) * BM + row] = areg[i].w;
+                As[adst[i] + 0] = areg[i].x; As[adst[i] + 1] = areg[i].y;
+                As[adst[i] + 2] = areg[i].z; As[adst[i] + 3] = areg[i].w;
             }
         }
 #pragma unroll
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256) void conv_tap(ConvArgs a) {
         for (int s = 0; s < BK / 2; s++) {
             float av[TM], bv[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; tm++) av[tm] = As[(2 * s + h) * BM + (wm * TM + tm) * 32 + r];
+            for (int tm = 0; tm < TM; tm++) av[tm] = As[((wm * TM + tm) * 32 + r) * LDA + 2 * s + h];
 #pragma unroll
             for (int tn = 0; tn < TN; tn++) bv[tn] = Bs[(2 * s + h) * BN + (wn * TN + tn) * 32 + r];
 #pragma unroll

@@ -509,10 +509,12 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         if (tid == 0) cursor = atomicAdd(&a.xcd_next[xcd], 1);   // in flight during phases 0-2, published at the barrier that ends phase 2
 
         // ---- phase 0: prefetched input tile -> RA as [42][42][3] ---------------------------------------------
+        if (!(a.dbg_skip & 16)) {
 #pragma unroll
         for (int i = 0; i < 7; i++) {        // p < 1792: the 28 pixels past the tile land in RA's tail (finite, never a live operand)
             float* d = RA + 3 * tid + 768 * i;
             d[0] = pre[i].x; d[1] = pre[i].y; d[2] = pre[i].z;
+        }
         }
         __syncthreads();
 
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 
         // next tile's input: global loads into registers only (RA is still read by phase 3)
         tile_nxt = __builtin_amdgcn_readfirstlane(next_tile_s);
-        if (tile_nxt < t_end) { nxt = decode(tile_nxt); issue_input(nxt); }
+        if (tile_nxt < t_end) { nxt = decode(tile_nxt); if (!(a.dbg_skip & 1)) issue_input(nxt); }
 
         // ---- phase 3: conv3 + PReLU -> per-wave staging -> heads -> candidates -------------------------------
         if (!(a.dbg_skip & 8)) {
