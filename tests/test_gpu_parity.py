@@ -236,6 +236,25 @@ def test_drift_score_matches_oracle(engine, oracle):
     assert np.array_equal(got["flags"].cpu().numpy(), ref["flags"])
 
 
+def test_drift_score_long_clip_crosses_scan_chunks(engine, oracle):
+    """The run-length scan stages similarities through LDS 4096 at a time: a 9,001-frame clip (three chunks, the last one
+    ragged) with runs that straddle the chunk borders and faceless stretches must score exactly like the oracle."""
+    rng = np.random.default_rng(10)
+    n = 9001
+    base = rng.standard_normal(512).astype(np.float32)
+    noise = np.where((np.arange(n) // 700) % 2 == 0, 0.6, 0.01).astype(np.float32)      # alternating drifting / steady stretches
+    emb = base[None, :] + rng.standard_normal((n, 512)).astype(np.float32) * noise[:, None]
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    valid = (rng.uniform(size=n) > 0.05).astype(np.uint8)
+    valid[4090:4100] = 0                                                                 # a faceless gap across the first border
+    for frame_count, fps in ((n * 4, 30), (n * 3 + 1, 25)):
+        ref = oracle.drift_score(emb, valid, frame_count, fps)
+        got = engine.drift_score(_t(emb), _t(valid), frame_count, fps)
+        assert (got["score"], got["run"], got["hits"]) == (ref["score"], ref["run"], ref["hits"])
+        assert np.array_equal(got["sims"].cpu().numpy(), ref["sims"]) and np.array_equal(got["flags"].cpu().numpy(), ref["flags"])
+    assert ref["hits"] > 100
+
+
 @pytest.mark.parametrize("byte", [0xFF, 0x7F])
 def test_results_do_not_depend_on_stale_memory(engine, oracle, byte):
     """Workspaces AND the LDS of every CU are filled with NaN (0xFF) / huge-float (0x7F) patterns before the call:
@@ -332,3 +351,31 @@ def test_batch_capacity_overflow_reruns_the_call(blob, oracle):
     rb, rp = oracle.detect(fr[0])
     k0 = int(c[0])
     assert (rb is None and k0 == 0) or np.array_equal(b[0, :k0].cpu().numpy(), rb)
+
+
+def test_multi_chunk_candidate_batches():
+    """R-/O-Net candidate batches larger than one launch set are processed in chunks (device-side `total - chunk_base` clamps).
+    With the chunk sizes shrunk to 16 / 16 candidates (fresh process: they are read once) a 360p clip needs many chunks, some of
+    them partially filled, some empty -- results must not change."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, truely_amd\n"
+        "from truely_amd.engine import Engine\n"
+        "from oracle.oracle import Oracle\n"
+        "blob = truely_amd.weights.synthetic_blob(0)\n"
+        "eng, orc = Engine(blob), Oracle(blob)\n"
+        "fr = truely_amd.synthetic.synthetic_frames(3, 360, 640, seed=11)\n"
+        "out, ref = eng.detect_embed(fr), orc.detect_embed(fr)\n"
+        "assert sum(eng.stage_boxes(1, i).shape[0] for i in range(3)) > 48    # several 16-candidate chunks, the last one ragged\n"
+        "for k in ('box', 'prob', 'rect', 'valid', 'emb'):\n"
+        "    assert np.array_equal(out[k].cpu().numpy(), ref[k]), k\n"
+        "for i in range(3):\n"
+        "    tr = orc.detect(fr[i], trace=True)[2]\n"
+        "    for s in (1, 2, 3):\n"
+        "        assert np.array_equal(eng.stage_boxes(s, i), tr['boxes%%d' %% s]), (i, s)\n"
+        "print('chunks ok')\n" % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, TRL_RNET_CHUNK="16", TRL_ONET_CHUNK="16")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0 and "chunks ok" in p.stdout, p.stderr[-2000:]

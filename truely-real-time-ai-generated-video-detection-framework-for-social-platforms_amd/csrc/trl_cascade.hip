@@ -12,10 +12,17 @@
 // All float expressions follow the reference's operation order (one rounding per op,
 // -ffp-contract=off), so boxes / keep masks are bit-identical to the oracle.
 #include "trl_ctx.h"
+#include <stdlib.h>
 
 // R-/O-Net candidates per launch set: one set covers a 256-frame batch (31 k / 8.5 k candidates), so no near-empty third chunk is
 // launched; scratch per chunk = 100 KB / 640 KB per candidate (5 / 8 GB at the cap, of 288 GB)
-constexpr int TRL_CH2 = 49152, TRL_CH3 = 12288;
+static int env_chunk(const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v >= 16 ? v : dflt;
+}
+// (TRL_RNET_CHUNK / TRL_ONET_CHUNK shrink a launch set for tests, so that the multi-chunk path runs on small inputs)
+static const int TRL_CH2 = env_chunk("TRL_RNET_CHUNK", 49152), TRL_CH3 = env_chunk("TRL_ONET_CHUNK", 12288);
 
 namespace {
 
