@@ -106,8 +106,8 @@ def cpu_baseline(frames_np, threads, cfg):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x 16 ms = a 1.6 s timed region by default)")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="sharded", choices=["sharded", "streams"])
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: the config's)")

@@ -9,8 +9,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh
 rm -rf $O && mkdir -p $O
 B="--no-cpu-baseline"
-timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench done"; cut -c1-300 $O/bench.json
-timeout -k 10 300 python bench.py --in-flight 1 $B > $O/bench_inflight1.json 2> $O/bench_inflight1.err
+timeout -k 10 400 python bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; echo "bench done"; cut -c1-300 $O/bench.json
+timeout -k 10 300 python bench.py --steps 10 --warmup 2 --in-flight 1 $B > $O/bench_inflight1.json 2> $O/bench_inflight1.err
 timeout -k 10 300 python bench.py --steps 400 --warmup 5 $B > $O/bench_sustained.json 2> $O/bench_sustained.err; echo "sustained done"
 timeout -k 10 300 python bench.py --config 2 --steps 10 --warmup 2 $B > $O/bench_config2.json 2> $O/bench_config2.err
 timeout -k 10 300 python bench.py --config 4 --steps 6 --warmup 2 $B > $O/bench_config4.json 2> $O/bench_config4.err
