@@ -14,19 +14,23 @@ sys.path.insert(0, ROOT)
 import truely_amd  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
 
-CASES = [  # name, n, H, W, seed
-    ("clip_180p", 6, 180, 320, 3),
-    ("clip_360p", 3, 360, 640, 11),
-    ("clip_odd", 3, 97, 131, 21),
-    ("clip_720p", 2, 720, 1280, 0),
+CASES = [  # name, n, H, W, seed, faces per frame (-1 = seeded 3..5)
+    ("clip_180p", 6, 180, 320, 3, 1),
+    ("clip_360p", 3, 360, 640, 11, 1),
+    ("clip_odd", 3, 97, 131, 21, 1),
+    ("clip_720p", 2, 720, 1280, 0, 1),
+    ("clip_multiface_270p", 2, 270, 480, 33, -1),
 ]
 
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     o = Oracle(truely_amd.weights.synthetic_blob(0))
-    for name, n, H, W, seed in CASES:
-        fr = truely_amd.synthetic.synthetic_frames(n, H, W, seed=seed)
+    only = sys.argv[1:]
+    for name, n, H, W, seed, faces in CASES:
+        if only and name not in only:
+            continue
+        fr = truely_amd.synthetic.synthetic_frames(n, H, W, seed=seed, faces=faces)
         r = o.detect_embed(fr, want_faces=True)
         d = o.drift_score(r["emb"], r["valid"], n * 4, 30)
         stages = {}
@@ -36,12 +40,14 @@ def main():
             stages[f"f{i}_keep"] = np.array(tr["n_keep_scale"], np.int32)
             for s in (1, 2, 3):
                 stages[f"f{i}_boxes{s}"] = tr[f"boxes{s}"]
-        np.savez_compressed(os.path.join(here, name + ".npz"), n=n, H=H, W=W, seed=seed,
+        np.savez_compressed(os.path.join(here, name + ".npz"), n=n, H=H, W=W, seed=seed, faces_per_frame=faces,
                             frames_crc=np.uint64(int(fr.astype(np.uint64).sum())),
                             box=r["box"], prob=r["prob"], rect=r["rect"], valid=r["valid"], emb=r["emb"],
                             faces=r["faces"], sims=d["sims"], flags=d["flags"], score=d["score"], run=d["run"], hits=d["hits"],
                             **stages)
         print(name, "valid", r["valid"].tolist(), "score", d["score"])
+    if only:
+        return
     # primitive vectors
     rng = np.random.default_rng(123)
     x = rng.uniform(0, 1, (2, 80, 80, 3)).astype(np.float32)

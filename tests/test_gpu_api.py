@@ -18,7 +18,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def test_hip_path_reproduces_golden(engine, path):
     z = np.load(path)
     n, H, W, seed = int(z["n"]), int(z["H"]), int(z["W"]), int(z["seed"])
-    fr = truely_amd.synthetic.synthetic_frames(n, H, W, seed=seed)
+    fr = truely_amd.synthetic.synthetic_frames(n, H, W, seed=seed, faces=int(z["faces_per_frame"]) if "faces_per_frame" in z else 1)
     out = engine.detect_embed(fr)
     for k in ("box", "prob", "rect", "valid", "emb"):
         assert np.array_equal(out[k].cpu().numpy(), z[k]), k

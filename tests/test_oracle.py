@@ -20,7 +20,8 @@ def test_oracle_reproduces_golden(oracle, path):
     n, H, W, seed = int(z["n"]), int(z["H"]), int(z["W"]), int(z["seed"])
     if H >= 720:
         n = 1   # keep the CPU suite short
-    fr = truely_amd.synthetic.synthetic_frames(int(z["n"]), H, W, seed=seed)[:n]
+    faces = int(z["faces_per_frame"]) if "faces_per_frame" in z else 1
+    fr = truely_amd.synthetic.synthetic_frames(int(z["n"]), H, W, seed=seed, faces=faces)[:n]
     if n == int(z["n"]):
         assert int(fr.astype(np.uint64).sum()) == int(z["frames_crc"]), "synthetic frame generator changed"
     r = oracle.detect_embed(fr, want_faces=True)

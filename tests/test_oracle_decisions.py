@@ -14,14 +14,15 @@ from decision_audit import audit_frame, merge_audits
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # name, n, H, W, seed, faces (-1 = seeded 3..5 faces per frame)
-STRESS = [("stress_200x150", 3, 200, 150, 22, 1), ("stress_64x333", 3, 64, 333, 23, 1), ("stress_multiface_270p", 2, 270, 480, 33, -1)]
+STRESS = [("stress_200x150", 3, 200, 150, 22, 1), ("stress_64x333", 3, 64, 333, 23, 1), ("stress_multiface_360p", 2, 360, 640, 34, -1)]
 
 
 def _cases():
     out = []
     for path in sorted(glob.glob(os.path.join(GOLD, "clip_*.npz"))):
         z = np.load(path)
-        out.append((os.path.basename(path)[:-4], int(z["n"]), int(z["H"]), int(z["W"]), int(z["seed"]), 1))
+        out.append((os.path.basename(path)[:-4], int(z["n"]), int(z["H"]), int(z["W"]), int(z["seed"]),
+                    int(z["faces_per_frame"]) if "faces_per_frame" in z else 1))
     return out + STRESS
 
 
