@@ -147,6 +147,10 @@ int  trl_debug_pnet_level(trl_ctx* ctx, const uint8_t* d_frame, int H, int W, in
  * = {logit0, logit1, reg[4], (landmarks[10])}. */
 int  trl_debug_rnet(trl_ctx* ctx, const float* d_crops, int n, float* d_out, void* stream);
 int  trl_debug_onet(trl_ctx* ctx, const float* d_crops, int n, float* d_out, void* stream);
+/* The production stage-2 / stage-3 network path (fused front kernel + layer tail) on caller-chosen boxes of ONE frame:
+ * h_boxes = nb host rows x1,y1,x2,y2 (as after rerec); net = 24 (R-Net, d_out [nb][6]) or 48 (O-Net, d_out [nb][16]). */
+int  trl_debug_front_net(trl_ctx* ctx, const uint8_t* d_frame, int H, int W, const float* h_boxes, int nb, int net,
+                         float* d_out, void* stream);
 /* model.py:55-58 alone: crop rect (x0,y0,x1,y1 per frame, i32) -> f32 [n][80][80][3] in [0,1] */
 int  trl_debug_crop_resize(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
                            const int32_t* d_rect, const uint8_t* d_valid, float* d_faces, void* stream);

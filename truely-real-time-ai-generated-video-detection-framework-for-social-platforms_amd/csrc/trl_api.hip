@@ -499,6 +499,49 @@ int trl_debug_rnet(trl_ctx* c, const float* d_crops, int n, float* d_out, void* 
     TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * 100 * 1024 + (4u << 20)));
     return trl_run_rnet(c, d_crops, n, d_out, (hipStream_t)stream);
 }
+// test hook: the PRODUCTION stage-2 / stage-3 network path on caller-chosen boxes of frame 0 -- the fused front kernel
+// (k_mtcnn_front: pad(), crop, area resample, conv1, PReLU, pool) followed by the layer tail -- so its crop paths (small boxes,
+// big boxes, boxes clipped by the frame) are checked directly, not only through cascade records.  h_boxes: nb rows of
+// x1,y1,x2,y2 (host); d_out: [nb][6] (net = 24) or [nb][16] (net = 48), device.
+int trl_debug_front_net(trl_ctx* c, const uint8_t* d_frame, int H, int W, const float* h_boxes, int nb, int net, float* d_out, void* stream) {
+    TRL_CHECK(check_call(c, d_frame, 1, H, W));
+    if (!h_boxes || !d_out || nb <= 0 || nb > c->cfg.cap_frame || (net != 24 && net != 48)) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    const int capF = c->cfg.cap_frame;
+    Arena& A = c->arena;
+    TRL_CHECK(trl_ensure(c, A, (size_t)capF * 20 + (size_t)capF * 8 + (1u << 20)));
+    A.reset();
+    CascadeBufs& B = c->cb;
+    B = CascadeBufs();
+    B.n = 1; B.H = H; B.W = W;
+    float* boxes = (float*)A.alloc((size_t)capF * 20);
+    B.map_frame = (int32_t*)A.alloc((size_t)capF * 4); B.map_local = (int32_t*)A.alloc((size_t)capF * 4);
+    int32_t* total = (int32_t*)A.alloc(64);
+    std::vector<float> hb((size_t)nb * 5, 0.f);
+    std::vector<int32_t> zeros(nb, 0), iota(nb);
+    for (int i = 0; i < nb; i++) { for (int q = 0; q < 4; q++) hb[5 * i + q] = h_boxes[4 * i + q]; iota[i] = i; }
+    TRL_HIP(hipMemcpyAsync(boxes, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, s));
+    TRL_HIP(hipMemcpyAsync(B.map_frame, zeros.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    TRL_HIP(hipMemcpyAsync(B.map_local, iota.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    TRL_HIP(hipMemcpyAsync(total, &nb, 4, hipMemcpyHostToDevice, s));
+    TRL_HIP(hipStreamSynchronize(s));                      // the host vectors go out of scope
+    c->scratch.reset();
+    TRL_CHECK(trl_ensure(c, c->scratch, (size_t)nb * 700 * 1024 + (4u << 20)));
+    if (net == 24) {
+        float* pool1 = (float*)c->scratch.alloc((size_t)nb * 11 * 11 * 28 * 4);
+        TRL_CHECK(trl_launch_rnet_front(c, d_frame, H, W, boxes, total, 0, nb, pool1, s));
+        TRL_CHECK(trl_run_rnet_tail(c, pool1, nb, d_out, s, total, 0));
+    } else {
+        float* pool1 = (float*)c->scratch.alloc((size_t)nb * 23 * 23 * 32 * 4);
+        TRL_CHECK(trl_launch_onet_front(c, d_frame, H, W, boxes, total, 0, nb, pool1, s));
+        TRL_CHECK(trl_run_onet_tail(c, pool1, nb, d_out, s, total, 0));
+    }
+    TRL_HIP(hipStreamSynchronize(s));
+    B = CascadeBufs();                                     // no cascade state to inspect after this hook
+    return TRL_OK;
+}
+
 int trl_debug_onet(trl_ctx* c, const float* d_crops, int n, float* d_out, void* stream) {
     if (!c || !c->have_weights || !d_crops || !d_out || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
     c->scratch.reset();

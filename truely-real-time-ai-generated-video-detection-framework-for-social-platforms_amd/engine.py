@@ -206,6 +206,16 @@ class Engine:
         _lib.check(self.lib.trl_debug_onet(self._h, _ptr(crops), crops.shape[0], _ptr(out), self._stream()))
         return out
 
+    def front_net(self, frame, boxes: np.ndarray, net: int) -> torch.Tensor:
+        """Test hook: R-Net (net=24 -> [nb, 6]) or O-Net (net=48 -> [nb, 16]) through the production front kernel + tail on the
+        given boxes (x1, y1, x2, y2) of one frame."""
+        fr = self._frames(frame[None] if getattr(frame, "ndim", 4) == 3 else frame)
+        _, H, W, _ = fr.shape
+        b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+        out = torch.empty((len(b), 6 if net == 24 else 16), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.trl_debug_front_net(self._h, _ptr(fr), H, W, b.ctypes.data_as(C.c_void_p), len(b), int(net), _ptr(out), self._stream()))
+        return out
+
     def crop_resize(self, frames, rect: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
         fr = self._frames(frames)
         n, H, W, _ = fr.shape
