@@ -8,7 +8,7 @@ sets = [truely_amd.synthetic.synthetic_frames(6, 180, 320, seed=3), truely_amd.s
         truely_amd.synthetic.synthetic_frames(8, 360, 640, seed=11), truely_amd.synthetic.synthetic_frames(16, 720, 1280, seed=0)]
 import sys
 mode = sys.argv[1] if len(sys.argv) > 1 else "default"
-eng = {"default": lambda: Engine(blob), "native": lambda: Engine(blob, embed_mode=2), "bf16": lambda: Engine(blob, embed_precision="bf16"),
+eng = {"default": lambda: Engine(blob), "native": lambda: Engine(blob, embed_mode=2), "bf16": lambda: Engine(blob, embed_precision="bf16"), "fp16": lambda: Engine(blob, embed_precision="fp16"),
        "generic_pnet": lambda: Engine(blob, pnet_mode=1)}[mode]()
 ref = []
 for fr in sets:
