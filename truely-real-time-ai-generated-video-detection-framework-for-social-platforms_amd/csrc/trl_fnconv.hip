@@ -461,22 +461,6 @@ __global__ __launch_bounds__(256) void fn_conv_split4(FnGroup g) {
 
 struct Tile { int bm, bn; };
 
-// Workgroup tile for an (M, N) problem: the grid should cover the 256 CUs in whole rounds.  cost = rounds x tile area
-// (+ a fixed per-workgroup term that favours fewer, larger tiles at equal area); padding waste enters through the ceilings.
-template <size_t NT>
-Tile choose_tile(int M, int N, const Tile (&menu)[NT]) {
-    Tile best = menu[0];
-    double bc = 1e30;
-    for (const Tile& t : menu) {
-        const long long wgs = (long long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
-        const long long rounds = (wgs + 255) / 256;
-        const double cost = (double)rounds * ((double)t.bm * t.bn + 600.0) + 0.02 * (double)(t.bm + t.bn) * 0;
-        const double tie = -1e-3 * (double)t.bm * t.bn;       // equal cost: larger tile (more operand reuse)
-        if (cost + tie < bc) { bc = cost + tie; best = t; }
-    }
-    return best;
-}
-
 template <int BM, int BN, int WM, int WN>
 void launch1(const FnGroup& g, int nz, hipStream_t s) {
     int gx = 0, gy = 0;
@@ -525,6 +509,17 @@ bool trl_fn_eligible(const ConvArgs& a) {
     return true;
 }
 
+// Workgroup tile by MEASUREMENT (tools/tune_fn_tiles.sh: every tile forced in turn under rocprofv3, per-launch times compared at the
+// 256-face geometry M = 12544 / 2304 / 256): these launches live on occupancy, not on operand reuse -- 32x32 tiles (many small
+// workgroups hide each other's load latency) beat the "whole rounds of 256 CUs" model of the first version by 13 % overall; the
+// exceptions are the four-chain layers on 3x3 maps, whose wave-private staging favours 48-row tiles for N <= 256.
+static Tile pick_tile(int M, int N, bool split4, int nz) {
+    if (!split4) return (M <= 4096 && N >= 512) ? Tile{64, 64} : Tile{32, 32};
+    if (nz > 1 || M <= 512) return Tile{16, 32};
+    if (M <= 4096) return N >= 384 ? Tile{32, 32} : (N >= 192 ? Tile{48, 64} : Tile{48, 32});
+    return Tile{32, 32};
+}
+
 // Up to three convs of the SAME class (all split-4 or all single-chain) in one launch; they must not depend on each other.
 int trl_launch_fn_group(const ConvArgs* convs, int nz, hipStream_t s) {
     if (nz < 1 || nz > 3) { trl_set_error("fn group size"); return TRL_ERR_INVALID; }
@@ -536,23 +531,15 @@ int trl_launch_fn_group(const ConvArgs* convs, int nz, hipStream_t s) {
         N += convs[z].Cout;                                  // the group shares the chip: choose the tile for the combined width
     }
     FnGroup g;
-    static const Tile menu1[] = {{32, 32}, {32, 64}, {64, 32}, {64, 64}, {64, 96}, {128, 32}, {128, 64}, {32, 128}, {16, 64}};
-    static const Tile menu4[] = {{16, 32}, {16, 64}, {32, 32}, {32, 64}, {48, 32}, {48, 64}};
+    // instantiated tiles: single chain {32,64,128}x{32,64,96,128} subset below; four chains {16,32,48}x{32,64}
     Tile t;
-    if (nz == 1) t = sp ? choose_tile(M, N, menu4) : choose_tile(M, N, menu1);
-    else {   // grouped: tiles of the convs are laid side by side in z, so rounds follow the SUM of their grids
-        Tile best{0, 0}; double bc = 1e30;
-        auto scan = [&](const Tile* menu, int nm) {
-            for (int i = 0; i < nm; i++) {
-                long long wgs = 0;
-                for (int z = 0; z < nz; z++) wgs += (long long)((convs[z].M + menu[i].bm - 1) / menu[i].bm) * ((convs[z].Cout + menu[i].bn - 1) / menu[i].bn);
-                const double cost = (double)((wgs + 255) / 256) * ((double)menu[i].bm * menu[i].bn + 600.0) - 1e-3 * menu[i].bm * menu[i].bn;
-                if (cost < bc) { bc = cost; best = menu[i]; }
-            }
-        };
-        if (sp) scan(menu4, (int)(sizeof menu4 / sizeof menu4[0])); else scan(menu1, (int)(sizeof menu1 / sizeof menu1[0]));
-        t = best;
-    }
+    // tuning aid: TRL_FN_FORCE1 / TRL_FN_FORCE4 = "BMxBN" forces the tile of every single-chain / four-chain launch
+    static const char* f1 = getenv("TRL_FN_FORCE1");
+    static const char* f4 = getenv("TRL_FN_FORCE4");
+    const char* force = sp ? f4 : f1;
+    int fbm = 0, fbn = 0;
+    if (force && sscanf(force, "%dx%d", &fbm, &fbn) == 2) t = Tile{fbm, fbn};
+    else t = pick_tile(M, nz == 1 ? convs[0].Cout : N, sp, nz);
     static const int skip = getenv("TRL_FN_SKIP") ? atoi(getenv("TRL_FN_SKIP")) : 0;
     g.skip = skip;
     g.dbg = nullptr;
