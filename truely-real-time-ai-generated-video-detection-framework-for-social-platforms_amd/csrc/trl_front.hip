@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
     __shared__ __attribute__((aligned(16))) float c1_s[MROWS * CLD];
     // per-wave column-sum strip (aliases c1_s, which is dead during the crop)
     constexpr int COLCAP = ((MROWS * CLD - 16) / 4 < 2048 ? (MROWS * CLD - 16) / 4 : 2048) & ~3;
-    static_assert(COLCAP >= 1024, "column strip too small");
+    static_assert(COLCAP >= 512, "column strip too small");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
@@ -370,9 +370,11 @@ int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     const DevV *b = trl_v(c, "rnet.conv1.b"), *sl = trl_v(c, "rnet.prelu1");
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("rnet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->rnet_front_mode < 0) c->rnet_front_mode = slope_mode(sl, 28);
-#define TRL_RF(MODE) k_mtcnn_front<24, 28, 4, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
+    static const int rr = getenv("TRL_RNET_R") ? atoi(getenv("TRL_RNET_R")) : 4;     // tuning aid: pooled rows per conv1 strip
+#define TRL_RF(RR, MODE) k_mtcnn_front<24, 28, RR, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
                                                                        c->cb.map_local, d_total, t0, w->p, b->p, sl->p, d_pool, front_dbg() & 3)
-    if (c->rnet_front_mode == 2) TRL_RF(2); else if (c->rnet_front_mode == 1) TRL_RF(1); else TRL_RF(0);
+    if (c->rnet_front_mode == 2) { if (rr == 2) TRL_RF(2, 2); else if (rr == 3) TRL_RF(3, 2); else if (rr == 6) TRL_RF(6, 2); else TRL_RF(4, 2); }
+    else if (c->rnet_front_mode == 1) TRL_RF(4, 1); else TRL_RF(4, 0);
 #undef TRL_RF
     TRL_LAUNCH_CHECK();
     return TRL_OK;
@@ -385,9 +387,12 @@ int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     const DevV *b = trl_v(c, "onet.conv1.b"), *sl = trl_v(c, "onet.prelu1");
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("onet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->onet_front_mode < 0) c->onet_front_mode = slope_mode(sl, 32);
-#define TRL_OF(MODE) k_mtcnn_front<48, 32, 3, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
+    static const int orr = getenv("TRL_ONET_R") ? atoi(getenv("TRL_ONET_R")) : 1;   // measured: one pooled row per strip = 49 KB of LDS = three resident
+                                                                                   // workgroups per CU: 1.18 vs 1.27 ms (R = 3, two per CU) for the O-Net front
+#define TRL_OF(RR, MODE) k_mtcnn_front<48, 32, RR, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
                                                                        c->cb.map_local, d_total, t0, w->p, b->p, sl->p, d_pool, (front_dbg() >> 2) & 3)
-    if (c->onet_front_mode == 2) TRL_OF(2); else if (c->onet_front_mode == 1) TRL_OF(1); else TRL_OF(0);
+    if (c->onet_front_mode == 2) { if (orr == 3) TRL_OF(3, 2); else if (orr == 2) TRL_OF(2, 2); else if (orr == 4) TRL_OF(4, 2); else TRL_OF(1, 2); }
+    else if (c->onet_front_mode == 1) TRL_OF(1, 1); else TRL_OF(1, 0);
 #undef TRL_OF
     TRL_LAUNCH_CHECK();
     return TRL_OK;

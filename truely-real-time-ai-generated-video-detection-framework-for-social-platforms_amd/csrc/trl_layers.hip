@@ -925,7 +925,8 @@ int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
         }
     }
     if (a.Cout <= 32) return deep ? launch_cfg<128, 32, 4, 1, 64>(a, vec, s) : launch_cfg<128, 32, 4, 1, 16>(a, vec, s);
-    if (a.M >= 16384) return deep ? launch_cfg<128, 64, 2, 2, 32>(a, vec, s) : launch_cfg<128, 64, 2, 2, 16>(a, vec, s);
+    static const int bigm = getenv("TRL_CONV_BIGM") ? atoi(getenv("TRL_CONV_BIGM")) : 128;   // tuning aid: row tile of the large-M layers
+    if (a.M >= 16384 && bigm == 128) return deep ? launch_cfg<128, 64, 2, 2, 32>(a, vec, s) : launch_cfg<128, 64, 2, 2, 16>(a, vec, s);
     if (a.M >= 1024) return deep ? launch_cfg<64, 64, 2, 2, 64>(a, vec, s) : launch_cfg<64, 64, 2, 2, 16>(a, vec, s);
     return deep ? launch_cfg<32, 128, 1, 4, 64>(a, vec, s) : launch_cfg<32, 128, 1, 4, 16>(a, vec, s);
 }
