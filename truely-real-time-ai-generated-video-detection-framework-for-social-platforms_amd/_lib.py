@@ -60,7 +60,7 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("TRUELY_HIP_LIB") or LIB_PATH      # (the override is a tuning aid: A/B of two builds on one box)
     if not os.path.exists(path):
         raise ImportError(f"{path} not found: build it with `make -C {_HERE}/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback")

@@ -32,7 +32,7 @@ struct FnGroup {
 namespace {
 
 constexpr int FBK = 32;                                   // K chunk: 32 channels of one filter tap
-constexpr int FDEPTH = 4;                                 // chunks in flight: these layers wait on the Infinity Cache / HBM round
+constexpr int FDEPTH = 2;                                 // chunks in flight: these layers wait on the Infinity Cache / HBM round
                                                           // trip of the previous layer's activations, not on bandwidth
 
 template <int... I, typename F>
