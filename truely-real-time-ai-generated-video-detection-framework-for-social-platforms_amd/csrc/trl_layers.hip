@@ -734,7 +734,8 @@ int launch_cfg(const ConvArgs& a, bool vec, hipStream_t s) {
     const long long x_elems = (long long)a.N * a.H * a.W * a.ldx + a.xoff;
     if (vec && !tap_off && a.K == a.KH * a.KW * a.Cin && x_elems < 0x7fffffffll && (long long)a.K * a.ldw < 0x7fffffffll) {
         if (BK >= 64 && a.Cin % 64 == 0) return launch_tap<BM, BN, WM, WN, 64>(a, grid, s);
-        if (a.Cin % 32 == 0) return launch_tap<BM, BN, WM, WN, 32>(a, grid, s);
+        static const bool bk16 = getenv("TRL_CONV_BK16") != nullptr;   // tuning aid: 16-channel chunks (half the LDS tile) where 32 divide Cin
+        if (a.Cin % 32 == 0 && !bk16) return launch_tap<BM, BN, WM, WN, 32>(a, grid, s);
         if (BM == 128 && BN == 64 && a.Cin % 28 == 0) return launch_tap<BM, BN, WM, WN, 28>(a, grid, s);
         if (a.Cin % 16 == 0) return launch_tap<BM, BN, WM, WN, 16>(a, grid, s);
     }
