@@ -321,3 +321,24 @@ def test_run_writes_annotations(engine, tmp_path, monkeypatch):
         if i % 4 == 0 and valid[i // 4]:
             seen_prev = True
     assert drawn >= 1
+
+
+def test_grouped_embedding_is_bit_identical(engine, blob):
+    """trl_detect_crop + ONE trl_facenet_embed_masked over several batches == trl_detect_embed per batch, bit for bit (every output
+    element is one accumulation chain, whatever tile / launch shape the larger batch selects), also through the pipelined host API."""
+    from truely_amd.engine import Engine
+    from truely_amd.model import analyze_video
+    from truely_amd.pipeline import detect_embed_grouped
+    fr = truely_amd.synthetic.synthetic_frames(12, 360, 640, seed=11)
+    fr[5] = 127                                              # a faceless frame: its row must be zero in both paths
+    ref = engine.detect_embed(fr)
+    batches = [fr[0:4], fr[4:8], fr[8:12]]
+    for G in (2, 3):
+        outs = detect_embed_grouped(engine, batches, G)
+        for k in ("box", "prob", "rect", "valid", "emb"):
+            assert torch.equal(torch.cat([o[k] for o in outs]), ref[k]), (G, k)
+        assert "faces" not in outs[0]
+    a = analyze_video(fr, fps=30, engine=engine, batch=4)
+    b = analyze_video(fr, fps=30, engines=[engine, Engine(blob)], batch=4, embed_group=2)
+    assert a["score"] == b["score"] and torch.equal(a["emb"], b["emb"]) and torch.equal(a["sims"], b["sims"])
+    assert not ref["valid"][5] and (ref["emb"][5] == 0).all()

@@ -29,6 +29,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p -f 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O/sq1 -o p -f csv -- python3 bench.py --steps 2 --warmup 1 $B --in-flight 1 > $O/sq1.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/sq2 -o p -f csv -- python3 bench.py --steps 2 --warmup 1 $B --in-flight 1 > $O/sq2.log 2>&1
 echo "pmc done"
-timeout -k 10 200 python tools/time_facenet.py > $O/facenet_ms.txt 2>&1
+timeout -k 10 200 python tools/time_facenet.py 20 256 > $O/facenet_ms.txt 2>&1
+timeout -k 10 200 python tools/time_facenet.py 10 768 >> $O/facenet_ms.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_fn768 -o s -f csv -- python3 tools/time_facenet.py 5 768 > $O/stats_fn768.log 2>&1
+timeout -k 10 300 python bench.py --steps 12 --warmup 3 --embed-group 1 $B > $O/bench_embed_group1.json 2> $O/bench_embed_group1.err
 timeout -k 10 200 python tools/fn_stamps.py 2 5 16 58 60 61 2>&1 | grep -E "launch|fn stamps" > $O/facenet_stamps.txt
 echo "facenet done"

@@ -355,24 +355,29 @@ int trl_facenet_embed(trl_ctx* c, const float* d_faces, int n, int h, int w, flo
     return trl_run_facenet(c, d_faces, n, h, w, nullptr, d_emb, (hipStream_t)stream);
 }
 
-int trl_detect_embed(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
-                     uint8_t* d_valid, float* d_emb, void* stream) {
+// model.py:47-58 (detect, largest box, crop + resize) and optionally :59 (embed).  d_faces_out != null: the crops are written there
+// (caller-owned [n][S][S][3] f32) and the embedder is NOT run (trl_detect_crop); else they live in scratch and are embedded.
+static int detect_embed_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
+                             uint8_t* d_valid, float* d_emb, float* d_faces_out, void* stream) {
     TRL_CHECK(check_call(c, d_frames, n, H, W));
-    if (!d_box || !d_prob || !d_rect || !d_valid || !d_emb) { trl_set_error("null output"); return TRL_ERR_INVALID; }
+    if (!d_box || !d_prob || !d_rect || !d_valid || (!d_emb && !d_faces_out)) { trl_set_error("null output"); return TRL_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     TRL_HIP(hipSetDevice(c->cfg.device));
     const int S = c->cfg.embed_mode == 0 ? 80 : 160;
-    c->scratch_after_cascade = (size_t)n * ((size_t)S * S * 110 + 400000) * 4 + (8u << 20);
+    c->scratch_after_cascade = d_faces_out ? 0 : (size_t)n * ((size_t)S * S * 110 + 400000) * 4 + (8u << 20);
     for (int attempt = 0;; attempt++) {
         TRL_HIP(hipEventRecord(c->ev_call0, s));
         TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
         TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, s));
-        c->scratch.reset();                          // stream order: the cascade's kernels are done with it before these run
-        float* faces = (float*)c->scratch.alloc((size_t)n * S * S * 3 * 4);
-        if (!faces) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
+        float* faces = d_faces_out;
+        if (!faces) {
+            c->scratch.reset();                      // stream order: the cascade's kernels are done with it before these run
+            faces = (float*)c->scratch.alloc((size_t)n * S * S * 3 * 4);
+            if (!faces) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
+        }
         if (c->cfg.embed_mode == 0) TRL_CHECK(trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, faces, s));
         else TRL_CHECK(trl_launch_crop_area_std(d_frames, n, H, W, d_rect, d_valid, S, c->cfg.embed_mode == 2, faces, s));
-        TRL_CHECK(trl_run_facenet(c, faces, n, S, S, d_valid, d_emb, s));
+        if (!d_faces_out) TRL_CHECK(trl_run_facenet(c, faces, n, S, S, d_valid, d_emb, s));
         TRL_HIP(hipEventRecord(c->ev_call1, s));
         TRL_HIP(hipStreamSynchronize(s));             // the call's one host synchronisation
         int retry = 0;
@@ -383,6 +388,27 @@ int trl_detect_embed(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, f
     }
     collect_timings(c);
     return TRL_OK;
+}
+
+int trl_detect_embed(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
+                     uint8_t* d_valid, float* d_emb, void* stream) {
+    if (!d_emb) { trl_set_error("null output"); return TRL_ERR_INVALID; }
+    return detect_embed_impl(c, d_frames, n, H, W, d_box, d_prob, d_rect, d_valid, d_emb, nullptr, stream);
+}
+
+int trl_detect_crop(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
+                    uint8_t* d_valid, float* d_faces, void* stream) {
+    if (!d_faces) { trl_set_error("null output"); return TRL_ERR_INVALID; }
+    return detect_embed_impl(c, d_frames, n, H, W, d_box, d_prob, d_rect, d_valid, nullptr, d_faces, stream);
+}
+
+int trl_facenet_embed_masked(trl_ctx* c, const float* d_faces, const uint8_t* d_valid, int n, int h, int w, float* d_emb, void* stream) {
+    if (!c || !c->have_weights) { trl_set_error("context without weights"); return TRL_ERR_STATE; }
+    if (!d_faces || !d_valid || !d_emb || n <= 0 || h < 75 || w < 75) { trl_set_error("bad face batch n=%d %dx%d (min 75x75)", n, h, w); return TRL_ERR_INVALID; }
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    c->scratch.reset();
+    TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * ((size_t)h * w * 110 + 400000) * 4 + (8u << 20)));
+    return trl_run_facenet(c, d_faces, n, h, w, d_valid, d_emb, (hipStream_t)stream);
 }
 
 int trl_drift_score(trl_ctx* c, const float* d_emb, const uint8_t* d_valid, int n, long long frame_count, int fps, float* d_sims,

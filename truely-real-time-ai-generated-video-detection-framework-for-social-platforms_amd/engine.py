@@ -113,6 +113,28 @@ class Engine:
                                              _ptr(out["valid"]), _ptr(out["emb"]), self._stream()))
         return out
 
+    # the two halves of detect_embed: callers that embed the faces of several batches in ONE embedder call (pipeline.py)
+    def detect_crop(self, frames):
+        fr = self._frames(frames)
+        n, H, W, _ = fr.shape
+        d = self.device
+        S = 80 if self.cfg.embed_mode == 0 else 160
+        out = {"box": torch.empty((n, 4), dtype=torch.float32, device=d), "prob": torch.empty((n,), dtype=torch.float32, device=d),
+               "rect": torch.empty((n, 4), dtype=torch.int32, device=d), "valid": torch.empty((n,), dtype=torch.uint8, device=d),
+               "faces": torch.empty((n, S, S, 3), dtype=torch.float32, device=d)}
+        _lib.check(self.lib.trl_detect_crop(self._h, _ptr(fr), n, H, W, _ptr(out["box"]), _ptr(out["prob"]), _ptr(out["rect"]),
+                                            _ptr(out["valid"]), _ptr(out["faces"]), self._stream()))
+        return out
+
+    def embed_faces(self, faces: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
+        """Embeddings of prepared crops (detect_crop's ``faces``), zero rows where ``valid`` is 0."""
+        faces = faces.to(self.device, torch.float32).contiguous()
+        valid = valid.to(self.device, torch.uint8).contiguous()
+        n, h, w, _ = faces.shape
+        emb = torch.empty((n, 512), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.trl_facenet_embed_masked(self._h, _ptr(faces), _ptr(valid), n, h, w, _ptr(emb), self._stream()))
+        return emb
+
     # SURVEY 8(f)-1: NV12 decoder output -> sampled BGR batch on the device (model.py:43,46)
     def ingest_nv12(self, nv12, H: int, W: int, step: int) -> torch.Tensor:
         if isinstance(nv12, np.ndarray):
