@@ -13,8 +13,9 @@ as a child, BEFORE anything here touches the GPU -- and exits with the child's c
   --mode streams          : BASELINE configs[3] -- one independent clip per GPU, no data-path collective.
   --config {1,2,4}        : which BASELINE.json configs[] entry the workload is (1 = headline, default).
   --ingest nv12           : supplementary leg: host NV12 -> pinned H2D -> BGR on the device -> the same path.
-  --embed-group G         : each worker embeds the faces of G of its steps in ONE InceptionResnetV1 call (default 3; detection, crops
-                            and every embedding are bit-identical to G = 1 -- the embedder's ~100 small launches amortise over more faces).
+  --embed-group G         : supplementary: each worker embeds the faces of G of its steps in ONE InceptionResnetV1 call (default 1 = per
+                            step; results are bit-identical for any G -- the embedder's ~100 small launches amortise over more faces, but on
+                            runs of 10-20 steps the pipeline's longer fill and drain cancel the gain).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -124,7 +125,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo to rehearse N>1 on one GPU")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="batches in flight per GPU: each gets its own context, HIP stream and host thread; 1 = strictly sequential")
-    ap.add_argument("--embed-group", type=int, default=3,
+    ap.add_argument("--embed-group", type=int, default=1,
                     help="steps whose faces each worker embeds in ONE InceptionResnetV1 call (trl_detect_crop per step, then one "
                          "trl_facenet_embed_masked): same bits, the embedder's ~100 small launches amortise over more faces")
     ap.add_argument("--master-port", type=int, default=None)

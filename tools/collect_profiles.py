@@ -40,7 +40,7 @@ def main():
     summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), os.path.join(SRC, "stats", "s_kernel_trace.csv"), "2", "--all"],
                           capture_output=True, text=True, check=True).stdout
     open(os.path.join(DST, f"{tag}_step_timeline_inflight1.txt"), "w").write(summ)
-    for name in ("bench_sustained", "bench_config2", "bench_config4", "bench_prelu_general", "bench_ingest_nv12", "bench_gloo2_sharded", "bench_gloo2_streams", "bench_embed_group1"):
+    for name in ("bench_sustained", "bench_config2", "bench_config4", "bench_prelu_general", "bench_ingest_nv12", "bench_gloo2_sharded", "bench_gloo2_streams", "bench_embed_group3"):
         src = os.path.join(SRC, name + ".json")
         if os.path.exists(src) and os.path.getsize(src) > 0:
             shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))

@@ -32,6 +32,6 @@ echo "pmc done"
 timeout -k 10 200 python tools/time_facenet.py 20 256 > $O/facenet_ms.txt 2>&1
 timeout -k 10 200 python tools/time_facenet.py 10 768 >> $O/facenet_ms.txt 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_fn768 -o s -f csv -- python3 tools/time_facenet.py 5 768 > $O/stats_fn768.log 2>&1
-timeout -k 10 300 python bench.py --steps 12 --warmup 3 --embed-group 1 $B > $O/bench_embed_group1.json 2> $O/bench_embed_group1.err
+timeout -k 10 300 python bench.py --steps 240 --warmup 6 --embed-group 3 $B > $O/bench_embed_group3.json 2> $O/bench_embed_group3.err
 timeout -k 10 200 python tools/fn_stamps.py 2 5 16 58 60 61 2>&1 | grep -E "launch|fn stamps" > $O/facenet_stamps.txt
 echo "facenet done"
