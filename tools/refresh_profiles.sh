@@ -9,8 +9,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh
 rm -rf $O && mkdir -p $O
 B="--no-cpu-baseline"
-timeout -k 10 400 python bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; echo "bench done"; cut -c1-300 $O/bench.json
-timeout -k 10 300 python bench.py --steps 10 --warmup 2 --in-flight 1 $B > $O/bench_inflight1.json 2> $O/bench_inflight1.err
+timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench done"; cut -c1-300 $O/bench.json
+timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 --in-flight 1 $B > $O/bench_inflight1.json 2> $O/bench_inflight1.err
 timeout -k 10 300 python bench.py --steps 400 --warmup 5 $B > $O/bench_sustained.json 2> $O/bench_sustained.err; echo "sustained done"
 timeout -k 10 300 python bench.py --config 2 --steps 10 --warmup 2 $B > $O/bench_config2.json 2> $O/bench_config2.err
 timeout -k 10 300 python bench.py --config 4 --steps 6 --warmup 2 $B > $O/bench_config4.json 2> $O/bench_config4.err
@@ -19,8 +19,8 @@ timeout -k 10 300 python bench.py --ingest nv12 --steps 10 $B > $O/bench_ingest_
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --steps 6 $B > $O/bench_gloo2_sharded.json 2> $O/bench_gloo2_sharded.err
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --mode streams --steps 6 $B > $O/bench_gloo2_streams.json 2> $O/bench_gloo2_streams.err
 echo "bench variants done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats2 -o s -f csv -- python3 bench.py --steps 6 --warmup 2 $B > $O/stats2.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o s -f csv -- python3 bench.py --steps 5 --warmup 2 $B --in-flight 1 > $O/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats2 -o s -f csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 $B > $O/stats2.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o s -f csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 $B --in-flight 1 > $O/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_c2 -o s -f csv -- python3 bench.py --config 2 --steps 4 --warmup 1 $B --in-flight 1 > $O/stats_c2.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_c4 -o s -f csv -- python3 bench.py --config 4 --steps 3 --warmup 1 $B --in-flight 1 > $O/stats_c4.log 2>&1
 echo "stats done"
