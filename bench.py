@@ -11,7 +11,7 @@ as a child, BEFORE anything here touches the GPU -- and exits with the child's c
   --mode sharded (default): one clip, contiguous time shards per rank, ONE all-gather (RCCL) of the embedding
                             rows per step, drift on every rank (weak scaling: per-GPU batch fixed);
   --mode streams          : BASELINE configs[3] -- one independent clip per GPU, no data-path collective.
-  --config {1,2,4}        : which BASELINE.json configs[] entry the workload is (1 = headline, default).
+  --config {0,1,2,4}      : which BASELINE.json configs[] entry the workload is (1 = headline, default).
   --ingest nv12           : supplementary leg: host NV12 -> pinned H2D -> BGR on the device -> the same path.
   --embed-group G         : supplementary: each worker embeds the faces of G of its steps in ONE InceptionResnetV1 call (default 1 = per
                             step; results are bit-identical for any G -- the embedder's ~100 small launches amortise over more faces, but on
@@ -35,6 +35,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32-input MFMA peak
 # BASELINE.json configs[] -> workload.  The detector is f32 in every config (a reduced-precision detector cannot
 # keep box / NMS index parity); configs[2] runs the embedder on the bf16 matrix cores.
 CONFIGS = {
+    0: dict(H=360, W=640, batch=240, faces=1, min_face=20, embed="f32", dtype="f32", unique=240,
+            name="BASELINE configs[0] shape: the 240 sampled frames (every 4th of 960) of a 640x360 30 fps clip in ONE batch, seeded "
+                 "synthetic frames (the reference's sample .mp4 cannot be decoded without OpenCV), fp32 -- the reference's own "
+                 "CPU-runnable case; a parity-test shape, not the headline"),
     1: dict(H=720, W=1280, batch=256, faces=1, min_face=20, embed="f32", dtype="f32", unique=256,
             name="BASELINE configs[1]: synthetic 720p 1-face frames, batch=256 per GPU, fp32, MTCNN detect + 80x80 crop + "
                  "InceptionResnetV1 embed + cosine drift score"),

@@ -55,7 +55,10 @@ typedef struct {
     int    pnet_mode;       /* 0 = fused PNet kernel, 1 = generic layer path (validation) */
     int    embed_mode;      /* 0 = reference: 80x80 INTER_LINEAR crop, BGR, /255 (model.py:41,57-58)  [default]
                              * 1 = SURVEY 8(f)-4 native mode: facenet-pytorch extract_face (160x160 area
-                             *     resample, .byte(), (x-127.5)/128), channel order kept; 2 = same, BGR->RGB */
+                             *     resample, .byte(), (x-127.5)/128), channel order kept; 2 = same, BGR->RGB
+                             * 3 = 8(f)-4 "landmark-aligned": 160x160 similarity warp of the largest face from its five
+                             *     O-Net landmarks to the scaled 112x112 five-point template (bilinear, replicated
+                             *     borders), (x-127.5)/128, RGB -- this project's definition, oracle: orc_crop_aligned */
     int    embed_precision; /* 0 = f32, bit-exact with the oracle                                        [default]
                              * 1 = bf16 activations/weights on the bf16 matrix cores for InceptionResnetV1 only
                              *     (BASELINE configs[2]); detector, crops and valid mask stay f32-exact; embeddings
@@ -163,6 +166,9 @@ int  trl_debug_front_net(trl_ctx* ctx, const uint8_t* d_frame, int H, int W, con
 /* model.py:55-58 alone: crop rect (x0,y0,x1,y1 per frame, i32) -> f32 [n][80][80][3] in [0,1] */
 int  trl_debug_crop_resize(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
                            const int32_t* d_rect, const uint8_t* d_valid, float* d_faces, void* stream);
+/* embed_mode 3's crop alone: d_pts [n][10] = x0..x4, y0..y4 per frame -> f32 [n][S][S][3] */
+int  trl_debug_crop_aligned(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W, const float* d_pts,
+                            const uint8_t* d_valid, int S, int rgb, float* d_faces, void* stream);
 /* Time (ms, HIP events on the call's stream) of the last trl_detect_embed call:
  * out[0] = PNet kernel (fused: the one persistent launch; generic: sum over levels),
  * out[1] = whole call, out[2] = number of PNet launches timed, out[3] = pyramid kernel. */

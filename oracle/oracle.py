@@ -191,6 +191,20 @@ class Oracle:
         self.lib.orc_crop_area_std(_p(img, C.c_uint8), H, W, x0, y0, x1, y1, int(S), int(bool(rgb)), _p(out))
         return out
 
+    def crop_aligned(self, img, pts, S=160, rgb=True):
+        """Five-point similarity-aligned crop (embedding mode 3); pts = x0..x4, y0..y4 in frame coordinates."""
+        img = np.ascontiguousarray(img, np.uint8); H, W = img.shape[:2]
+        pts = np.ascontiguousarray(pts, np.float32).reshape(10)
+        out = np.empty((S, S, 3), np.float32)
+        self.lib.orc_crop_aligned(_p(img, C.c_uint8), H, W, _p(pts), int(S), int(bool(rgb)), _p(out))
+        return out
+
+    def align_params(self, pts):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(10)
+        prm = np.empty((6,), np.float64)
+        self.lib.orc_align_params(_p(pts), prm.ctypes.data_as(C.POINTER(C.c_double)))
+        return prm
+
     def drift_score(self, emb, valid, frame_count, fps):
         emb = np.ascontiguousarray(emb, np.float32); valid = np.ascontiguousarray(valid, np.uint8)
         n = len(valid)

@@ -922,6 +922,55 @@ void orc_crop_area_std(const uint8_t* img, int H, int W, int x0, int y0, int x1,
     }
 }
 
+/* SURVEY 8(f)-4, "landmark-aligned": this project's own definition (facenet-pytorch does not align; the reference discards the
+ * landmarks, server/model.py:47).  The five O-Net points (left eye, right eye, nose, mouth corners) are matched to the 112x112
+ * five-point template everyone uses for face embedders, scaled to SxS = 160: least-squares SIMILARITY (scale, rotation,
+ * translation) from template coordinates to frame coordinates, estimated directly as the inverse map the warp needs:
+ *     d_j = T_j - mean(T),  e_j = P_j - mean(P),  a = sum(d.e)/sum|d|^2,  b = sum(dx*ey - dy*ex)/sum|d|^2,
+ *     x(u,v) = a*(u-Tx) - b*(v-Ty) + Px,   y(u,v) = b*(u-Tx) + a*(v-Ty) + Py          (all in double, this order)
+ * then a bilinear sample of the u8 frame with replicated borders (float: p00 + fx*(p01-p00), rows likewise), no byte
+ * quantisation, fixed_image_standardization (v-127.5)/128, optional BGR -> RGB. */
+static const double ORC_TPL_X[5] = {54.706571428571436, 105.04542857142857, 80.036, 59.35614285714286, 101.04271428571428};
+static const double ORC_TPL_Y[5] = {73.85185714285714, 73.57342857142856, 102.48085714285713, 131.9507142857143, 131.72014285714286};
+void orc_align_params(const float* pts, double* prm) {
+    double tx = 0., ty = 0., px = 0., py = 0.;
+    for (int j = 0; j < 5; j++) { tx += ORC_TPL_X[j]; ty += ORC_TPL_Y[j]; px += (double)pts[j]; py += (double)pts[5 + j]; }
+    tx = tx / 5.; ty = ty / 5.; px = px / 5.; py = py / 5.;
+    double sdd = 0., sde = 0., scr = 0.;
+    for (int j = 0; j < 5; j++) {
+        const double dx = ORC_TPL_X[j] - tx, dy = ORC_TPL_Y[j] - ty, ex = (double)pts[j] - px, ey = (double)pts[5 + j] - py;
+        sdd = sdd + (dx * dx + dy * dy);
+        sde = sde + (dx * ex + dy * ey);
+        scr = scr + (dx * ey - dy * ex);
+    }
+    prm[0] = sde / sdd; prm[1] = scr / sdd; prm[2] = tx; prm[3] = ty; prm[4] = px; prm[5] = py;
+}
+void orc_crop_aligned(const uint8_t* img, int H, int W, const float* pts, int S, int rgb, float* out) {
+    double prm[6];
+    orc_align_params(pts, prm);
+    const double a = prm[0], b = prm[1];
+    for (int v = 0; v < S; v++) {
+        for (int u = 0; u < S; u++) {
+            const double du = (double)u - prm[2], dv = (double)v - prm[3];
+            const double x = (a * du - b * dv) + prm[4], y = (b * du + a * dv) + prm[5];
+            const double xf = floor(x), yf = floor(y);
+            const float fx = (float)(x - xf), fy = (float)(y - yf);
+            /* clamp in double first: a degenerate point set can send the coordinates anywhere */
+            const double xc = (xf >= -1.) ? (xf > (double)W ? (double)W : xf) : -1., yc = (yf >= -1.) ? (yf > (double)H ? (double)H : yf) : -1.;   /* NaN -> -1 */
+            int x0 = (int)xc, y0 = (int)yc, x1 = x0 + 1, y1 = y0 + 1;
+            x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+            y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+            const uint8_t *r0 = img + (size_t)y0 * W * 3, *r1 = img + (size_t)y1 * W * 3;
+            for (int c = 0; c < 3; c++) {
+                const float p00 = (float)r0[x0 * 3 + c], p01 = (float)r0[x1 * 3 + c], p10 = (float)r1[x0 * 3 + c], p11 = (float)r1[x1 * 3 + c];
+                const float top = p00 + fx * (p01 - p00), bot = p10 + fx * (p11 - p10);
+                const float val = top + fy * (bot - top);
+                out[((size_t)v * S + u) * 3 + (rgb ? 2 - c : c)] = (val - 127.5f) / 128.0f;
+            }
+        }
+    }
+}
+
 int orc_detect_embed_mode(const orc_ctx* c, const uint8_t* frames, int n, int H, int W, const orc_params* P, int mode,
                           float* box_out, float* prob_out, int32_t* rect_out, uint8_t* valid_out, float* emb_out) {
     if (mode == 0) return orc_detect_embed(c, frames, n, H, W, P, box_out, prob_out, rect_out, valid_out, emb_out, NULL);
@@ -930,10 +979,29 @@ int orc_detect_embed_mode(const orc_ctx* c, const uint8_t* frames, int n, int H,
     for (int i = 0; i < n; i++) {
         const uint8_t* fr = frames + (size_t)i * H * W * 3;
         float bx[4 * 64], pr[64];
-        int k = orc_detect(c, fr, H, W, P, bx, pr, 64, NULL);
+        orc_trace tr;
+        memset(&tr, 0, sizeof tr);
+        float *tb3 = NULL, *tp3 = NULL;
+        if (mode == 3) {          /* the landmarks of the largest face come out of the stage-3 trace */
+            tr.max_boxes = 4096;
+            tb3 = (float*)malloc(sizeof(float) * 5 * tr.max_boxes); tp3 = (float*)malloc(sizeof(float) * 10 * tr.max_boxes);
+            tr.boxes3 = tb3; tr.points3 = tp3;
+        }
+        int k = orc_detect(c, fr, H, W, P, bx, pr, 64, mode == 3 ? &tr : NULL);
         memset(box_out + 4 * i, 0, 16); memset(rect_out + 4 * i, 0, 16);
         prob_out[i] = 0.f; valid_out[i] = 0;
         memset(emb_out + (size_t)i * 512, 0, 2048);
+        float pts0[10] = {0};
+        if (mode == 3 && k > 0) {  /* rank 0 of argsort(area)[::-1] with stable ties: largest area, ties -> higher index */
+            int best = 0; float ba = -1.f;
+            const int m = tr.n3 < tr.max_boxes ? tr.n3 : tr.max_boxes;
+            for (int q = 0; q < m; q++) {
+                const float ar = (tb3[5 * q + 2] - tb3[5 * q]) * (tb3[5 * q + 3] - tb3[5 * q + 1]);
+                if (ar >= ba) { ba = ar; best = q; }
+            }
+            memcpy(pts0, tp3 + 10 * best, sizeof pts0);
+        }
+        free(tb3); free(tp3);
         if (k <= 0) continue;
         memcpy(box_out + 4 * i, bx, 16);
         prob_out[i] = pr[0];
@@ -945,7 +1013,8 @@ int orc_detect_embed_mode(const orc_ctx* c, const uint8_t* frames, int n, int H,
         rect_out[4 * i] = (int32_t)b0; rect_out[4 * i + 1] = (int32_t)b1; rect_out[4 * i + 2] = (int32_t)b2; rect_out[4 * i + 3] = (int32_t)b3;
         if (!(b2 > b0 && b3 > b1)) continue;
         float* face = (float*)malloc((size_t)S * S * 3 * sizeof(float));
-        orc_crop_area_std(fr, H, W, (int)b0, (int)b1, (int)b2, (int)b3, S, mode == 2, face);
+        if (mode == 3) orc_crop_aligned(fr, H, W, pts0, S, 1, face);
+        else orc_crop_area_std(fr, H, W, (int)b0, (int)b1, (int)b2, (int)b3, S, mode == 2, face);
         orc_facenet(c, face, 1, S, S, emb_out + (size_t)i * 512);
         free(face);
         valid_out[i] = 1;

@@ -112,6 +112,9 @@ int   orc_drift_score(const float* emb, const uint8_t* valid, int n, long frame_
 /* mode 0 = reference (80x80 INTER_LINEAR, BGR, /255); 1 = facenet-pytorch extract_face for tensor
  * input (160x160 area resample, .byte(), (x-127.5)/128), BGR kept; 2 = the same with BGR->RGB. */
 void  orc_crop_area_std(const uint8_t* img, int H, int W, int x0, int y0, int x1, int y1, int S, int rgb, float* out);
+/* mode 3 of orc_detect_embed_mode: five-point similarity alignment (see trl_oracle.c); prm = {a, b, Tx, Ty, Px, Py} */
+void  orc_align_params(const float* pts, double* prm);
+void  orc_crop_aligned(const uint8_t* img, int H, int W, const float* pts, int S, int rgb, float* out);
 int   orc_detect_embed_mode(const orc_ctx*, const uint8_t* frames, int n, int H, int W, const orc_params*, int mode,
                             float* box_out, float* prob_out, int32_t* rect_out, uint8_t* valid_out, float* emb_out);
 

@@ -109,6 +109,35 @@ def test_bad_arguments_are_rejected(engine):
         engine.facenet_embed(torch.zeros(1, 40, 40, 3))            # too small for the stem
 
 
+def test_malformed_weight_blobs_are_rejected(blob):
+    """trl_load_weights trusts nothing in the blob's directory: bad magic, a truncated blob, an entry whose byte range leaves the
+    blob, a shape that does not account for the entry's bytes and a missing tensor are all TRL_ERR_WEIGHTS, not a crash."""
+    import struct
+    from truely_amd.engine import Engine
+    from truely_amd._lib import TrlError
+    from truely_amd import weights
+    (n,) = struct.unpack_from("<I", blob, 8)
+    ent = weights._ENTRY
+
+    def patched(i, **kw):
+        b = bytearray(blob)
+        f = list(ent.unpack_from(b, 16 + i * ent.size))
+        for k, v in kw.items():
+            f[{"ndim": 1, "d0": 2, "d1": 3, "off": 6, "nb": 7}[k]] = v
+        ent.pack_into(b, 16 + i * ent.size, *f)
+        return bytes(b)
+    name, ndim, d0, d1, _, _, off, nb = ent.unpack_from(blob, 16)
+    bad = [b"XXXXXXXX" + blob[8:], blob[:16 + ent.size * n - 8], patched(0, off=len(blob) - 4), patched(0, off=2 ** 63, nb=2 ** 63),
+           patched(0, d0=d0 + 1), patched(0, nb=nb - 4)]
+    t = weights.unpack_tensors(blob)
+    t.pop("pnet.conv4_2.w")
+    bad.append(weights.pack_tensors(t))
+    for b in bad:
+        with pytest.raises(TrlError) as e:
+            Engine(b)
+        assert e.value.status == -3, str(e.value)               # TRL_ERR_WEIGHTS
+
+
 def test_nv12_ingest_with_sampling(engine, oracle):
     """NV12 -> BGR of every step-th frame on the device equals the oracle per frame."""
     rng = np.random.default_rng(12)
@@ -123,10 +152,42 @@ def test_nv12_ingest_with_sampling(engine, oracle):
         engine.ingest_nv12(nv12[:, :-3], H, W, step)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+def test_aligned_crop_kernel_bit_exact(engine, oracle):
+    """Embedding mode 3's crop on chosen landmark sets: upright, rotated, scaled, partly outside the frame (replicated borders),
+    degenerate (all five points equal: scale 0, every sample is one pixel) -- device = oracle bit for bit, and an exact
+    template (identity transform, up to the f32 rounding of the points) reproduces the frame's top-left 160x160 pixels."""
+    rng = np.random.default_rng(5)
+    H, W = 300, 420
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    tx = np.array([54.706571428571436, 105.04542857142857, 80.036, 59.35614285714286, 101.04271428571428])
+    ty = np.array([73.85185714285714, 73.57342857142856, 102.48085714285713, 131.9507142857143, 131.72014285714286])
+
+    def place(scale, deg, cx, cy, jitter=0.0):
+        t = np.deg2rad(deg)
+        x = (tx - 80.0) * scale, (ty - 102.7) * scale
+        px = np.cos(t) * x[0] - np.sin(t) * x[1] + cx + rng.normal(0, jitter, 5)
+        py = np.sin(t) * x[0] + np.cos(t) * x[1] + cy + rng.normal(0, jitter, 5)
+        return np.concatenate([px, py]).astype(np.float32)
+    sets = [np.concatenate([tx, ty]).astype(np.float32), place(1.0, 0, 200, 150), place(0.6, 17, 210, 140, 1.5), place(1.7, -33, 100, 220, 2.0),
+            place(2.5, 5, 10, 10), place(1.2, 180, 400, 280, 1.0), place(0.3, 90, 415, 3), np.full(10, 123.25, np.float32),
+            place(40.0, 45, 5000, -3000)]
+    pts = torch.from_numpy(np.stack(sets))
+    n = len(sets)
+    valid = torch.ones(n, dtype=torch.uint8); valid[3] = 0
+    frames = np.broadcast_to(img, (n, H, W, 3)).copy()
+    for rgb in (True, False):
+        got = engine.crop_aligned(frames, pts, valid, rgb=rgb).cpu().numpy()
+        for i in range(n):
+            ref = oracle.crop_aligned(img, sets[i], rgb=rgb) if valid[i] else np.zeros((160, 160, 3), np.float32)
+            assert np.array_equal(got[i], ref), (i, rgb)
+    ident = engine.crop_aligned(frames[:1], pts[:1], valid[:1], rgb=False).cpu().numpy()[0]
+    assert np.abs(ident - (img[:160, :160].astype(np.float32) - 127.5) / 128).max() < 1e-3
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_native_embedding_mode(blob, oracle, mode):
-    """SURVEY 8(f)-4: 160x160 area-resampled, standardised (optionally RGB) crops behind a flag;
-    the default (mode 0) stays the reference's 80x80 BGR /255 path."""
+    """160x160 area-resampled, standardised (optionally RGB) crops behind a flag (modes 1, 2) and the
+    landmark-aligned RGB crop (mode 3); the default (mode 0) stays the reference's 80x80 BGR /255 path."""
     from truely_amd.engine import Engine
     eng = Engine(blob, embed_mode=mode)
     fr = truely_amd.synthetic.synthetic_frames(3, 360, 640, seed=11)

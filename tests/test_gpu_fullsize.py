@@ -54,6 +54,33 @@ def test_drift_is_a_function_of_time_order_only(engine, clip720):
     assert d0["score"] == d1["score"] and torch.equal(d0["sims"], d1["sims"]) and torch.equal(d0["flags"], d1["flags"])
 
 
+def test_config0_whole_clip_through_run(engine, oracle, tmp_path, monkeypatch):
+    """BASELINE configs[0] at its stated shape through the drop-in boundary: a 960-frame 640x360 30 fps clip, `run()` samples
+    every 4th frame (240 analysed), streams them in windows and writes all 960 frames.  The reference's sample .mp4 cannot be
+    decoded here, so the clip is seeded synthetic frames in the raw container: 12 distinct frames, each held for 80 frames, so
+    the oracle's per-frame results (frames are independent up to the drift scan) give the expected score of the whole clip."""
+    from truely_amd import engine as eng_mod, model, video_io
+    monkeypatch.setattr(eng_mod, "_default", engine)
+    monkeypatch.setenv("TRUELY_ANNOTATE", "0")
+    H, W, fps, N = 360, 640, 30, 960
+    uniq = truely_amd.synthetic.synthetic_frames(12, H, W, seed=21)
+    src, dst = str(tmp_path / "c0.trlv"), str(tmp_path / "c0_out.trlv")
+    wr = video_io.RawWriter(src, fps, (W, H))
+    for i in range(N):
+        wr.write(uniq[i // 80])
+    wr.release()
+    score = model.run(src, dst)
+    r = oracle.detect_embed(uniq)
+    idx = np.arange(0, N, 4) // 80                                   # the 240 sampled frames
+    d = oracle.drift_score(r["emb"][idx], r["valid"][idx], N, fps)
+    assert len(idx) == 240 and score == d["score"]
+    rd, ofps, ow, oh = video_io.open_reader(dst)
+    assert (ofps, ow, oh, rd.n) == (fps, W, H, N)
+    # and as ONE 240-frame batch (bench.py --config 0): same embeddings as the oracle's, frame for frame
+    out = engine.detect_embed(uniq[idx])
+    assert np.array_equal(out["emb"].cpu().numpy(), r["emb"][idx]) and np.array_equal(out["valid"].cpu().numpy(), r["valid"][idx])
+
+
 _FRAME_CACHE = {}
 
 

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "trl_debug_onet": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "trl_debug_front_net": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "trl_debug_crop_resize": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "trl_debug_crop_aligned": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "trl_debug_timings": (C.c_int, [_vp, C.POINTER(_f)]),
     "trl_debug_pnet_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
 }

@@ -38,7 +38,7 @@ int trl_default_config(trl_config* cfg) {
 int trl_create(const trl_config* cfg, trl_ctx** out) {
     if (!cfg || !out) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
     if (cfg->cap_level < 64 || cfg->cap_level > 3072 || cfg->cap_frame < 64 || cfg->cap_frame > 3072 || (cfg->cap_level & 3) ||
-        (cfg->cap_frame & 3) || cfg->min_face_size < 12 || cfg->max_faces < 1 || !(cfg->factor > 0.1 && cfg->factor < 0.99) || cfg->embed_mode < 0 || cfg->embed_mode > 2 ||
+        (cfg->cap_frame & 3) || cfg->min_face_size < 12 || cfg->max_faces < 1 || !(cfg->factor > 0.1 && cfg->factor < 0.99) || cfg->embed_mode < 0 || cfg->embed_mode > 3 ||
         cfg->embed_precision < 0 || cfg->embed_precision > 2) {
         trl_set_error("bad trl_config (capacities must be multiples of 4 in [64,3072], min_face_size >= 12)");
         return TRL_ERR_INVALID;
@@ -48,11 +48,13 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
     c->cfg = *cfg;
     // diagnostic only: the clocked PNet instantiation (device-wall-clock span of the launch) runs when TRL_PNET_CLOCK is set
     if (getenv("TRL_PNET_CLOCK") && hipMalloc((void**)&c->pnet_clk, 16) != hipSuccess) c->pnet_clk = nullptr;
-    TRL_HIP(hipMalloc((void**)&c->pnet_cursor, 64));
-    if (hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess) { delete c; trl_set_error("hipHostMalloc failed"); return TRL_ERR_HIP; }
+    if (hipMalloc((void**)&c->pnet_cursor, 64) != hipSuccess || hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess ||
+        hipEventCreate(&c->ev_call0) != hipSuccess || hipEventCreate(&c->ev_call1) != hipSuccess) {
+        trl_set_error("context allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        trl_destroy(c);                      // frees whatever was created
+        return TRL_ERR_HIP;
+    }
     memset(c->h_pinned, 0, 256);
-    (void)hipEventCreate(&c->ev_call0);
-    (void)hipEventCreate(&c->ev_call1);
     *out = c;
     return TRL_OK;
 }
@@ -143,8 +145,14 @@ extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
     std::unordered_map<std::string, const Entry*> idx;
     for (uint32_t i = 0; i < nt; i++) {
         const Entry& e = ent[i];
-        if (e.offset + e.nbytes > nbytes) { trl_set_error("tensor out of blob bounds"); return TRL_ERR_WEIGHTS; }
+        if (e.offset > nbytes || e.nbytes > nbytes - e.offset || (e.offset & 3)) { trl_set_error("tensor out of blob bounds"); return TRL_ERR_WEIGHTS; }
         std::string name(e.name, strnlen(e.name, 56));
+        // the declared shape must account for exactly the bytes the entry owns (the copies below trust the shape)
+        const uint64_t elems = e.ndim == 2 ? (uint64_t)e.dims[0] * e.dims[1] : (e.ndim == 1 ? (uint64_t)e.dims[0] : 0);
+        if ((e.ndim == 1 || e.ndim == 2) && (elems == 0 || elems > (1ull << 31) || elems * 4 != e.nbytes)) {
+            trl_set_error("tensor '%s': shape and byte count disagree", name.c_str());
+            return TRL_ERR_WEIGHTS;
+        }
         idx[name] = &e;
         const float* src = (const float*)(b + e.offset);
         if (e.ndim == 2) add_mat(name, (int)e.dims[0], (int)e.dims[1], src);
@@ -160,14 +168,16 @@ extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
             auto ib = idx.find(net + "." + p + ".b");
             if (it == idx.end() || ib == idx.end()) { trl_set_error("missing head %s.%s", net.c_str(), p.c_str()); return TRL_ERR_WEIGHTS; }
             if (K < 0) K = (int)it->second->dims[0];
+            if (K != (int)it->second->dims[0] || ib->second->dims[0] != it->second->dims[1]) {
+                trl_set_error("head %s.%s has an unexpected shape", net.c_str(), p.c_str());
+                return TRL_ERR_WEIGHTS;
+            }
             tot += (int)it->second->dims[1];
         }
         keep_alive.emplace_back((size_t)K * tot);
-        std::vector<float>& w = keep_alive.back();
-        keep_alive.emplace_back((size_t)tot);
+        keep_alive.emplace_back((size_t)tot);       // (keep_alive is reserved below: the references stay valid)
         std::vector<float>& bias = keep_alive[keep_alive.size() - 1];
         std::vector<float>& wm = keep_alive[keep_alive.size() - 2];
-        (void)w;
         int col = 0;
         for (auto& p : parts) {
             const Entry* e = idx[net + "." + p + ".w"];
@@ -333,7 +343,7 @@ static int mtcnn_detect_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, 
         TRL_HIP(hipMemsetAsync(d_boxes, 0, (size_t)n * c->cfg.max_faces * 16, s));
         TRL_HIP(hipMemsetAsync(d_probs, 0, (size_t)n * c->cfg.max_faces * 4, s));
         if (d_points) TRL_HIP(hipMemsetAsync(d_points, 0, (size_t)n * c->cfg.max_faces * 40, s));
-        TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, d_boxes, d_probs, d_points, d_counts, box0, prob0, rect, valid, s));
+        TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, d_boxes, d_probs, d_points, d_counts, box0, prob0, rect, valid, nullptr, s));
         TRL_HIP(hipEventRecord(c->ev_call1, s));
         TRL_HIP(hipStreamSynchronize(s));             // the call's one host synchronisation
         int retry = 0;
@@ -368,7 +378,12 @@ static int detect_embed_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, 
     for (int attempt = 0;; attempt++) {
         TRL_HIP(hipEventRecord(c->ev_call0, s));
         TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
-        TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, s));
+        float* pts0 = nullptr;
+        if (c->cfg.embed_mode == 3) {                // the largest face's landmarks steer the aligned crop
+            pts0 = (float*)c->arena.alloc((size_t)n * 40);
+            if (!pts0) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
+        }
+        TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, pts0, s));
         float* faces = d_faces_out;
         if (!faces) {
             c->scratch.reset();                      // stream order: the cascade's kernels are done with it before these run
@@ -376,6 +391,7 @@ static int detect_embed_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, 
             if (!faces) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
         }
         if (c->cfg.embed_mode == 0) TRL_CHECK(trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, faces, s));
+        else if (c->cfg.embed_mode == 3) TRL_CHECK(trl_launch_crop_aligned(d_frames, n, H, W, pts0, d_valid, S, true, faces, s));
         else TRL_CHECK(trl_launch_crop_area_std(d_frames, n, H, W, d_rect, d_valid, S, c->cfg.embed_mode == 2, faces, s));
         if (!d_faces_out) TRL_CHECK(trl_run_facenet(c, faces, n, S, S, d_valid, d_emb, s));
         TRL_HIP(hipEventRecord(c->ev_call1, s));
@@ -425,7 +441,10 @@ int trl_drift_score(trl_ctx* c, const float* d_emb, const uint8_t* d_valid, int 
 
 // ---- inspection hooks ----------------------------------------------------------------------------------
 int trl_debug_stage_boxes(trl_ctx* c, int stage, int frame, float* h_boxes, int max_rows, int* n_out) {
-    if (!c || !c->cb.n1 || frame < 0 || frame >= c->cb.n || stage < 1 || stage > 3) { trl_set_error("no cascade state"); return TRL_ERR_STATE; }
+    if (!c || !c->cb.n1 || frame < 0 || frame >= c->cb.n || stage < 1 || stage > 3 || !n_out || (max_rows > 0 && !h_boxes)) {
+        trl_set_error("no cascade state");
+        return TRL_ERR_STATE;
+    }
     const int32_t* cnt = stage == 1 ? c->cb.n1 : (stage == 2 ? c->cb.n2 : c->cb.n3);
     const float* src = stage == 1 ? c->cb.s1_box : (stage == 2 ? c->cb.s2_box : c->cb.s3_box);
     int32_t k = 0;
@@ -464,7 +483,7 @@ int trl_debug_poison(trl_ctx* c, int byte) {
 }
 
 int trl_debug_level_counts(trl_ctx* c, int frame, int32_t* h_cand, int32_t* h_keep, int* n_levels) {
-    if (!c || !c->cb.lvl_cnt || frame < 0 || frame >= c->cb.n) { trl_set_error("no cascade state"); return TRL_ERR_STATE; }
+    if (!c || !c->cb.lvl_cnt || frame < 0 || frame >= c->cb.n || !h_cand || !h_keep || !n_levels) { trl_set_error("no cascade state"); return TRL_ERR_STATE; }
     TRL_HIP(hipDeviceSynchronize());
     const int L = c->cb.L;
     TRL_HIP(hipMemcpy(h_cand, c->cb.lvl_cnt + (size_t)frame * L, (size_t)L * 4, hipMemcpyDeviceToHost));
@@ -578,6 +597,12 @@ int trl_debug_crop_resize(trl_ctx* c, const uint8_t* d_frames, int n, int H, int
                           float* d_faces, void* stream) {
     if (!c || !d_frames || !d_rect || !d_valid || !d_faces || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
     return trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, d_faces, (hipStream_t)stream);
+}
+// embedding mode 3's crop alone: d_pts [n][10] (x0..x4, y0..y4 per frame) -> f32 [n][S][S][3]
+int trl_debug_crop_aligned(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, const float* d_pts, const uint8_t* d_valid, int S,
+                           int rgb, float* d_faces, void* stream) {
+    if (!c || !d_frames || !d_pts || !d_valid || !d_faces || n <= 0 || H < 1 || W < 1 || S < 1) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    return trl_launch_crop_aligned(d_frames, n, H, W, d_pts, d_valid, S, rgb != 0, d_faces, (hipStream_t)stream);
 }
 // test hook: set the optimistic R-/O-Net batch capacities (candidates per frame) the next call starts from, and read back how
 // many attempts the last call needed (> 1: a capacity was too small and the call was re-run with a larger one)

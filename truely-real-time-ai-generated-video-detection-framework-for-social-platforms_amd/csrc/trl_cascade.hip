@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64) void k_select(int capF, int max_faces, int W, i
                                                const float* __restrict__ s3_box, const float* __restrict__ s3_pts,
                                                float* __restrict__ boxes, float* __restrict__ probs, float* __restrict__ points,
                                                int32_t* __restrict__ counts, float* __restrict__ box0, float* __restrict__ prob0,
-                                               int32_t* __restrict__ rect, uint8_t* __restrict__ valid) {
+                                               int32_t* __restrict__ rect, uint8_t* __restrict__ valid, float* __restrict__ pts0) {
     const int f = blockIdx.x;
     const int n = n3[f];
     const float* b = s3_box + (size_t)f * capF * 5;
@@ -485,6 +485,10 @@ __global__ __launch_bounds__(64) void k_select(int capF, int max_faces, int W, i
             if (y1 > H) y1 = H;
             rect[4 * f] = (int)x0; rect[4 * f + 1] = (int)y0; rect[4 * f + 2] = (int)x1; rect[4 * f + 3] = (int)y1;
             valid[f] = (x1 > x0 && y1 > y0) ? 1 : 0;   // model.py:54
+            if (pts0) {                                 // embedding mode 3: the largest face's five landmarks
+                const float* ps = s3_pts + ((size_t)f * capF + r) * 10;
+                for (int q = 0; q < 10; q++) pts0[10 * f + q] = ps[q];
+            }
         }
     }
     if (threadIdx.x == 0) {
@@ -492,6 +496,7 @@ __global__ __launch_bounds__(64) void k_select(int capF, int max_faces, int W, i
         if (n == 0 && box0) {
             for (int q = 0; q < 4; q++) { box0[4 * f + q] = 0.f; rect[4 * f + q] = 0; }
             prob0[f] = 0.f; valid[f] = 0;
+            if (pts0) for (int q = 0; q < 10; q++) pts0[10 * f + q] = 0.f;
         }
     }
 }
@@ -572,6 +577,54 @@ __global__ __launch_bounds__(256) void k_crop_area_std(const uint8_t* __restrict
     o[3 * p + (rgb ? 0 : 2)] = (b2 - 127.5f) / 128.0f;
 }
 
+// SURVEY 8(f)-4 "landmark-aligned" embedding mode (trl_config.embed_mode 3; this project's own definition, restated in
+// oracle/trl_oracle.c orc_crop_aligned): least-squares similarity from the scaled 112x112 five-point template to the face's
+// O-Net landmarks, estimated as the inverse map (double, fixed operation order), bilinear sample of the u8 frame with
+// replicated borders (float), (v-127.5)/128, optional BGR -> RGB.  One thread per output pixel; every thread of a face
+// recomputes the six transform parameters (60 flops) rather than paying a second launch.
+__constant__ double TPL_X[5] = {54.706571428571436, 105.04542857142857, 80.036, 59.35614285714286, 101.04271428571428};
+__constant__ double TPL_Y[5] = {73.85185714285714, 73.57342857142856, 102.48085714285713, 131.9507142857143, 131.72014285714286};
+__global__ __launch_bounds__(256) void k_crop_aligned(const uint8_t* __restrict__ frames, int H, int W, const float* __restrict__ pts0,
+                                                      const uint8_t* __restrict__ valid, int S, int rgb, float* __restrict__ out) {
+    const int f = blockIdx.y;
+    float* o = out + (size_t)f * S * S * 3;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= S * S) return;
+    if (!valid[f]) { o[3 * p] = 0.f; o[3 * p + 1] = 0.f; o[3 * p + 2] = 0.f; return; }
+    const float* pts = pts0 + 10 * f;
+    double tx = 0., ty = 0., px = 0., py = 0.;
+#pragma unroll
+    for (int j = 0; j < 5; j++) { tx += TPL_X[j]; ty += TPL_Y[j]; px += (double)pts[j]; py += (double)pts[5 + j]; }
+    tx = tx / 5.; ty = ty / 5.; px = px / 5.; py = py / 5.;
+    double sdd = 0., sde = 0., scr = 0.;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const double dx = TPL_X[j] - tx, dy = TPL_Y[j] - ty, ex = (double)pts[j] - px, ey = (double)pts[5 + j] - py;
+        sdd = sdd + (dx * dx + dy * dy);
+        sde = sde + (dx * ex + dy * ey);
+        scr = scr + (dx * ey - dy * ex);
+    }
+    const double a = sde / sdd, b = scr / sdd;
+    const int v = p / S, u = p - v * S;
+    const double du = (double)u - tx, dv = (double)v - ty;
+    const double x = (a * du - b * dv) + px, y = (b * du + a * dv) + py;
+    const double xf = floor(x), yf = floor(y);
+    const float fx = (float)(x - xf), fy = (float)(y - yf);
+    const double xc = (xf >= -1.) ? (xf > (double)W ? (double)W : xf) : -1., yc = (yf >= -1.) ? (yf > (double)H ? (double)H : yf) : -1.;   // NaN -> -1
+    int x0 = (int)xc, y0 = (int)yc, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    const uint8_t* fp = frames + (size_t)f * H * W * 3;
+    const uint8_t *r0 = fp + (size_t)y0 * W * 3, *r1 = fp + (size_t)y1 * W * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float p00 = (float)r0[x0 * 3 + c], p01 = (float)r0[x1 * 3 + c], p10 = (float)r1[x0 * 3 + c], p11 = (float)r1[x1 * 3 + c];
+        const float top = p00 + fx * (p01 - p00), bot = p10 + fx * (p11 - p10);
+        const float val = top + fy * (bot - top);
+        o[3 * p + (rgb ? 2 - c : c)] = (val - 127.5f) / 128.0f;
+    }
+}
+
 template <typename K>
 int set_dyn_smem(K kernel, size_t bytes) {
     TRL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -621,6 +674,13 @@ int trl_launch_crop_area_std(const uint8_t* d_frames, int n, int H, int W, const
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
+int trl_launch_crop_aligned(const uint8_t* d_frames, int n, int H, int W, const float* d_pts0, const uint8_t* d_valid, int S, bool rgb,
+                            float* d_faces, hipStream_t s) {
+    if (n <= 0) return TRL_OK;
+    k_crop_aligned<<<dim3((S * S + 255) / 256, n), 256, 0, s>>>(d_frames, H, W, d_pts0, d_valid, S, rgb ? 1 : 0, d_faces);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+}
 int trl_launch_crop_resize80(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid,
                              float* d_faces, hipStream_t s) {
     if (n <= 0) return TRL_OK;
@@ -640,7 +700,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     Arena& A = c->arena;      // cascade lists: live for the whole call (and for the debug hooks after it)
     Arena& X = c->scratch;    // activations: reset between stages
     const size_t need = (size_t)n * L * ((size_t)cap * (sizeof(Cand) + 4) + 8) + (size_t)n * capF * (5 * 3 + 10 + 2) * 4 +
-                        (size_t)n * 128 + (1u << 20);
+                        (size_t)n * 1024 + (1u << 20);   // + the API layer's per-frame outputs (box0, prob0, rect, valid, pts0)
     TRL_CHECK(trl_ensure(c, A, need));
     A.reset();
     B.lvl_cnt = (int32_t*)A.alloc((size_t)n * L * 4);
@@ -792,11 +852,11 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
 }
 
 int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, float* d_points,
-                       int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, hipStream_t s) {
+                       int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, float* d_pts0, hipStream_t s) {
     (void)d_frames;
     CascadeBufs& B = c->cb;
     k_select<<<n, 64, 0, s>>>(c->cfg.cap_frame, c->cfg.max_faces, W, H, B.n3, B.s3_box, B.s3_pts, d_boxes, d_probs, d_points, d_counts, d_box0, d_prob0,
-                              d_rect, d_valid);
+                              d_rect, d_valid, d_pts0);
     TRL_LAUNCH_CHECK();
     // overflow flags + stage totals travel to pinned host memory behind the kernels; trl_cascade_check reads them after the
     // call's ONE stream synchronisation (no host round trip inside the call)

@@ -84,10 +84,12 @@ size_t trl_pnet_generic_bytes(int nf, int h, int w);
 // cascade (trl_cascade.hip)
 int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipStream_t s);
 int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, float* d_points,
-                       int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, hipStream_t s);
+                       int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, float* d_pts0, hipStream_t s);
 int trl_cascade_check(trl_ctx* c, int n, int* retry);   // after the call's stream synchronisation
 int trl_launch_crop_resize80(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid,
                              float* d_faces, hipStream_t s);
+int trl_launch_crop_aligned(const uint8_t* d_frames, int n, int H, int W, const float* d_pts0, const uint8_t* d_valid, int S, bool rgb,
+                            float* d_faces, hipStream_t s);
 int trl_launch_crop_area_std(const uint8_t* d_frames, int n, int H, int W, const int32_t* d_rect, const uint8_t* d_valid, int S,
                              bool rgb, float* d_faces, hipStream_t s);
 int trl_launch_area_level(const uint8_t* d_frames, int nf, int H, int W, int h, int w, float* d_level, hipStream_t s);

@@ -1183,12 +1183,17 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         TRL_HIP(hipMemsetAsync(c->pnet_clk + 1, 0, 8, s));
     }
     if (ev) TRL_HIP(hipEventRecord(ev[2], s));   // the event pair brackets the kernel alone (HIP events on the launch's stream)
+    static const int xlds = getenv("TRL_PNET_XLDS") ? atoi(getenv("TRL_PNET_XLDS")) : 0;   // experiment: unused dynamic LDS, lowers the resident workgroups per CU
+    if (xlds > 0) {
+        (void)hipFuncSetAttribute((const void*)k_pnet_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, xlds);
+        (void)hipFuncSetAttribute((const void*)k_pnet_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, xlds);
+    }
     if (c->pnet_clk) {
-        if (c->pnet_unit) k_pnet_fused<true, true><<<grid, 256, 0, s>>>(a);
-        else k_pnet_fused<false, true><<<grid, 256, 0, s>>>(a);
+        if (c->pnet_unit) k_pnet_fused<true, true><<<grid, 256, xlds, s>>>(a);
+        else k_pnet_fused<false, true><<<grid, 256, xlds, s>>>(a);
     } else {
-        if (c->pnet_unit) k_pnet_fused<true, false><<<grid, 256, 0, s>>>(a);
-        else k_pnet_fused<false, false><<<grid, 256, 0, s>>>(a);
+        if (c->pnet_unit) k_pnet_fused<true, false><<<grid, 256, xlds, s>>>(a);
+        else k_pnet_fused<false, false><<<grid, 256, xlds, s>>>(a);
     }
     TRL_LAUNCH_CHECK();
     if (ev) TRL_HIP(hipEventRecord(ev[3], s));

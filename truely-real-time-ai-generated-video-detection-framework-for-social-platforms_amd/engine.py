@@ -246,6 +246,18 @@ class Engine:
         _lib.check(self.lib.trl_debug_crop_resize(self._h, _ptr(fr), n, H, W, _ptr(rect), _ptr(valid), _ptr(out), self._stream()))
         return out
 
+    def crop_aligned(self, frames, pts: torch.Tensor, valid: torch.Tensor, S: int = 160, rgb: bool = True) -> torch.Tensor:
+        """Embedding mode 3's crop alone: five-point similarity alignment of each frame's face (pts [n,10] = x0..x4, y0..y4)."""
+        fr = self._frames(frames)
+        n, H, W, _ = fr.shape
+        pts = pts.to(self.device, torch.float32).contiguous(); valid = valid.to(self.device, torch.uint8).contiguous()
+        if pts.shape != (n, 10) or valid.shape != (n,):
+            raise ValueError("pts must be (n, 10) and valid (n,)")
+        out = torch.empty((n, S, S, 3), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.trl_debug_crop_aligned(self._h, _ptr(fr), n, H, W, _ptr(pts), _ptr(valid), int(S), int(bool(rgb)), _ptr(out),
+                                                   self._stream()))
+        return out
+
     def levels(self, H: int, W: int) -> int:
         """Number of pyramid levels MTCNN.detect builds for an (H, W) frame (detect_face.py scale loop)."""
         m = 12.0 / self.cfg.min_face_size
