@@ -359,6 +359,24 @@ def test_run_nv12_device_ingest(engine, oracle, tmp_path, monkeypatch):
         assert ok and np.array_equal(got, bgr[i])
 
 
+def test_run_reads_y4m(engine, tmp_path, monkeypatch):
+    """The same clip as YUV4MPEG2 (what `ffmpeg -pix_fmt yuv420p clip.y4m` writes) and as an NV12 TRLV file: same score, same
+    written frames -- the planes are repacked to NV12 and take the device ingest."""
+    from truely_amd import engine as eng_mod, model, video_io
+    from truely_amd.ingest import bgr_to_nv12
+    monkeypatch.setattr(eng_mod, "_default", engine)
+    monkeypatch.setattr(model, "BATCH", 4)
+    monkeypatch.setenv("TRUELY_ANNOTATE", "0")
+    H, W, fps = 180, 320, 30
+    nv = bgr_to_nv12(truely_amd.synthetic.synthetic_frames(22, H, W, seed=3))
+    a, b = str(tmp_path / "in.trlv"), str(tmp_path / "in.y4m")
+    video_io.write_raw(a, nv, fps, pixfmt="nv12", size=(W, H))
+    video_io.write_y4m(b, nv, fps, (W, H))
+    sa, sb = model.run(a, str(tmp_path / "oa.trlv")), model.run(b, str(tmp_path / "ob.trlv"))
+    assert sa == sb
+    assert open(str(tmp_path / "oa.trlv"), "rb").read() == open(str(tmp_path / "ob.trlv"), "rb").read()
+
+
 def test_run_writes_annotations(engine, tmp_path, monkeypatch):
     """Sampled frames that were compared with a predecessor carry a box (model.py:67-74); the others are untouched."""
     from truely_amd import engine as eng_mod, model, video_io

@@ -216,6 +216,31 @@ def test_cascade_fused_pnet_odd_sizes(engine, oracle):
         _check_cascade(engine, oracle, truely_amd.synthetic.synthetic_frames(3, H, W, seed=seed))
 
 
+def test_frames_at_and_below_the_smallest_pyramid(engine, oracle):
+    """min(H, W) * 12 / min_face_size < 12 (short side under 20 px at the default): detect_face() builds NO scale and reports no
+    face -- the device path must do the same, not divide by a zero tile count.  At exactly 20 px there is one 13x13 level with
+    a 2x2 PNet map; elongated strips give one-tile-high levels.  thr0 = 0 makes every PNet cell a candidate, so the tiny levels'
+    records, NMS and stage boxes are compared, not just 'nothing found'."""
+    from truely_amd.engine import Engine
+    import oracle.oracle as orc_mod
+    blob = engine._blob
+    eng0 = Engine(blob, thresholds=(0.0, 0.7, 0.7), cap_level=3072, cap_frame=3072)
+    orc0 = orc_mod.Oracle(blob)
+    orc0.params.thr0 = 0.0
+    for (H, W, seed) in [(12, 12, 1), (19, 19, 2), (16, 200, 3), (20, 20, 4), (21, 33, 5), (20, 700, 6), (500, 23, 7)]:
+        fr = np.random.default_rng(seed).integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+        small = min(H, W) < 20
+        assert (engine.levels(H, W) == 0) == small
+        for eng, orc in ((engine, oracle), (eng0, orc0)):
+            if small:
+                got, ref = eng.detect_embed(fr), orc.detect_embed(fr)
+                for k in ("box", "prob", "rect", "valid", "emb"):
+                    assert np.array_equal(got[k].cpu().numpy(), ref[k]), (H, W, k)
+                assert not got["valid"].any() and int(eng.mtcnn_detect(fr)[2].sum()) == 0
+            else:
+                _check_cascade(eng, orc, fr)
+
+
 @pytest.mark.parametrize("variant", ["slopes_above_one", "negative_slopes"])
 def test_cascade_fused_pnet_prelu_variants(variant):
     """PReLU slopes outside [0, 1] take the generic kernel instantiation; a negative conv1 slope also forbids

@@ -303,3 +303,36 @@ def test_mp4_probe_reference_sample():
         n += 1
     assert n == 960 and idr >= 1
     assert max(1, int(int(i.fps) / 7)) == 4                   # model.py:40 -> 240 sampled frames
+
+
+def test_y4m_reader_repacks_planes_to_nv12(tmp_path):
+    """YUV4MPEG2 4:2:0 in, flat NV12 out (what the device ingest consumes); header variants; unsupported streams are 'cannot open'."""
+    rng = np.random.default_rng(3)
+    H, W, n = 6, 8, 5
+    nv = rng.integers(0, 256, (n, H * W * 3 // 2), dtype=np.uint8)
+    p = str(tmp_path / "a.y4m")
+    video_io.write_y4m(p, nv, 25, (W, H))
+    rd, fps, w, h = video_io.open_reader(p)
+    assert (fps, w, h, rd.n, rd.pixfmt) == (25, W, H, n, "nv12")
+    for i in range(n):
+        ok, fr = rd.read()
+        assert ok and np.array_equal(fr, nv[i])
+    assert rd.read()[0] is False
+    rd.release()
+    # planar layout on disk: Y, then U, then V
+    raw = open(p, "rb").read()
+    body = raw[raw.index(b"\n") + 1:]
+    assert body[:6] == b"FRAME\n" and body[6:6 + H * W] == nv[0][:H * W].tobytes()
+    assert body[6 + H * W:6 + H * W + (H // 2) * (W // 2)] == nv[0][H * W::2].tobytes()
+    # NTSC-style rational rate, frame parameters, no C tag (defaults to 4:2:0)
+    q = str(tmp_path / "b.y4m")
+    with open(q, "wb") as f:
+        f.write(b"YUV4MPEG2 W8 H6 F30000:1001 Ip A1:1\n")
+        f.write(b"FRAME\n" + bytes(H * W * 3 // 2))
+    rd, fps, w, h = video_io.open_reader(q)
+    assert fps == 29 and rd.read()[0]                     # int(fps) like model.py:28
+    for bad in (b"YUV4MPEG2 W8 H6 F30:1 Ip C444\n", b"YUV4MPEG2 W8 H6 F30:1 It C420jpeg\n", b"YUV4MPEG2 W6 H6 F30:1 Ip C420jpeg\n",
+                b"YUV4MPEG2 W8 H6 F30:1 Ip C420p10\n"):
+        r = str(tmp_path / "bad.y4m")
+        open(r, "wb").write(bad + b"FRAME\n" + bytes(100))
+        assert video_io.open_reader(r) is None

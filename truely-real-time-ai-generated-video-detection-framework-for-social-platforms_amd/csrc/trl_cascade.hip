@@ -714,8 +714,19 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     B.map_frame = (int32_t*)A.alloc((size_t)n * capF * 4); B.map_local = (int32_t*)A.alloc((size_t)n * capF * 4);
     B.flags = (int32_t*)A.alloc(64);
     if (!B.flags) { trl_set_error("cascade workspace allocation failed"); return TRL_ERR_STATE; }
-    TRL_HIP(hipMemsetAsync(B.lvl_cnt, 0, (size_t)n * L * 4, s));
     TRL_HIP(hipMemsetAsync(B.flags, 0, 64, s));
+    if (L == 0) {
+        // min(H, W) * 12 / min_face_size < 12: detect_face() builds no scale at all and returns no boxes (the frame is smaller
+        // than the smallest face looked for).  Every stage count is zero; k_select then reports "no face" for every frame.
+        TRL_HIP(hipMemsetAsync(B.n1, 0, (size_t)n * 4, s));
+        TRL_HIP(hipMemsetAsync(B.n2, 0, (size_t)n * 4, s));
+        TRL_HIP(hipMemsetAsync(B.n3, 0, (size_t)n * 4, s));
+        TRL_HIP(hipMemsetAsync(B.off2, 0, (size_t)(n + 1) * 4, s));
+        TRL_HIP(hipMemsetAsync(B.off3, 0, (size_t)(n + 1) * 4, s));
+        if (c->scratch_after_cascade) TRL_CHECK(trl_ensure(c, X, c->scratch_after_cascade));   // the crops + embedder of the same call
+        return TRL_OK;
+    }
+    TRL_HIP(hipMemsetAsync(B.lvl_cnt, 0, (size_t)n * L * 4, s));
 
     // ---- stage 1: PNet over the pyramid ----------------------------------------------------------
     c->pnet_ev_used = 0;

@@ -776,6 +776,7 @@ int trl_pnet_prepare(trl_ctx* c) {
 static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<uint32_t>* tab = nullptr) {
     const int L = trl_compute_levels(c, H, W);
     if (L > 16) { trl_set_error("more than 16 pyramid levels"); return TRL_ERR_INVALID; }
+    if (L < 1) { trl_set_error("frame %dx%d has no pyramid level at min_face_size %d", W, H, c->cfg.min_face_size); return TRL_ERR_INVALID; }
     a.n_frames = n; a.L = L; a.H = H; a.W = W;
     int tiles = 0, ntab = 0; long long pix = 0, work = 0;
     for (int l = 0; l < L; l++) {

@@ -81,7 +81,7 @@ def run(video_path_one: str, video_path_two: str) -> int:
     eng = default_engine()
     nv12 = getattr(cap, "pixfmt", "bgr") == "nv12"
     write_out = os.environ.get("TRUELY_WRITE_OUTPUT", "1") != "0"
-    sink = video_io.open_writer(video_path_two, fps, (width, height), isinstance(cap, video_io.RawReader)) if write_out else None
+    sink = video_io.open_writer(video_path_two, fps, (width, height), isinstance(cap, (video_io.RawReader, video_io.Y4MReader))) if write_out else None
     writer = video_io.AsyncWriter(sink, annotate=os.environ.get("TRUELY_ANNOTATE", "1") != "0")
     step = max(1, int(fps / 7))   # model.py:40
     frame_count = 0

@@ -6,7 +6,9 @@ the build environment, so two back-ends exist behind the same tiny interface:
 
 * ``cv2`` when importable (real .mp4 in, annotated .mp4 out, like the reference);
 * the raw "TRLV" container (fps header + uint8 frames, BGR or -- what a hardware decoder hands over -- NV12) used by the
-  tests and the benchmark.  NV12 clips take the device ingest path of ``model.run``.
+  tests and the benchmark.  NV12 clips take the device ingest path of ``model.run`` (SURVEY section 8(f) rank 1);
+* YUV4MPEG2 (``.y4m``, 4:2:0 progressive): the uncompressed interchange format every decoder can emit
+  (``ffmpeg -i clip.mp4 -pix_fmt yuv420p clip.y4m``).  Planes are repacked to NV12 on the fly and take the same device ingest.
 ``AsyncWriter`` is the decoupled, skippable annotated-output stage: drawing and encoding run on their
 own thread behind a bounded queue, so the analysis loop never waits for the encoder (the reference draws and encodes inline,
 server/model.py:67-77).
@@ -60,6 +62,78 @@ class RawReader:
 
     def release(self):
         self.f.close()
+
+
+class Y4MReader:
+    """YUV4MPEG2 4:2:0 progressive.  ``read()`` yields flat NV12 frames (Y plane, then interleaved U/V) like an NV12 TRLV clip."""
+    pixfmt = "nv12"
+
+    def __init__(self, path):
+        self.f = open(path, "rb")
+        line = self.f.readline(256)
+        if not line.startswith(b"YUV4MPEG2 ") or not line.endswith(b"\n"):
+            self.f.close()
+            raise ValueError("not a YUV4MPEG2 file")
+        self.width = self.height = 0
+        self.fps_f = 0.0
+        chroma, interlace = "420jpeg", "p"
+        for tok in line[10:].split():
+            t, v = chr(tok[0]), tok[1:].decode("ascii", "replace")
+            if t == "W":
+                self.width = int(v)
+            elif t == "H":
+                self.height = int(v)
+            elif t == "F":
+                num, _, den = v.partition(":")
+                self.fps_f = int(num) / max(1, int(den or 1))
+            elif t == "C":
+                chroma = v
+            elif t == "I":
+                interlace = v
+        if not chroma.startswith("420") or chroma.startswith("420p1") or interlace not in ("p", "?"):
+            self.f.close()
+            raise ValueError(f"unsupported YUV4MPEG2 stream (chroma {chroma}, interlace {interlace}): 8-bit 4:2:0 progressive only")
+        if self.width <= 0 or self.height <= 0 or self.width % 4 or self.height % 2:
+            self.f.close()
+            raise ValueError(f"YUV4MPEG2 {self.width}x{self.height}: the NV12 ingest needs W % 4 == 0 and even H")
+        self.header = len(line)
+        self.ysize, self.csize = self.width * self.height, (self.width // 2) * (self.height // 2)
+        self.frame_bytes = self.ysize + 2 * self.csize
+        self.n = max(0, (os.path.getsize(path) - self.header) // (6 + self.frame_bytes))   # "FRAME\n" + planes (no frame params)
+        self.i = 0
+
+    def isOpened(self):
+        return True
+
+    def read(self):
+        tag = self.f.readline(256)
+        if not tag.startswith(b"FRAME"):
+            return False, None
+        buf = self.f.read(self.frame_bytes)
+        if len(buf) < self.frame_bytes:
+            return False, None
+        self.i += 1
+        a = np.frombuffer(buf, np.uint8)
+        out = np.empty(self.frame_bytes, np.uint8)
+        out[:self.ysize] = a[:self.ysize]
+        out[self.ysize::2] = a[self.ysize:self.ysize + self.csize]          # U
+        out[self.ysize + 1::2] = a[self.ysize + self.csize:]                # V
+        return True, out
+
+    def release(self):
+        self.f.close()
+
+
+def write_y4m(path, nv12_frames: np.ndarray, fps: int, size):
+    """Test / tooling helper: flat NV12 frames -> a YUV4MPEG2 file (planar 4:2:0)."""
+    w, h = size
+    ys = w * h
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{w} H{h} F{int(fps)}:1 Ip A1:1 C420jpeg\n".encode())
+        for fr in nv12_frames:
+            fr = np.asarray(fr, np.uint8).reshape(-1)
+            f.write(b"FRAME\n")
+            f.write(fr[:ys].tobytes()); f.write(fr[ys::2].tobytes()); f.write(fr[ys + 1::2].tobytes())
 
 
 class RawWriter:
@@ -136,6 +210,13 @@ def open_reader(path):
         magic = f.read(8)
     if magic == _MAGIC:
         r = RawReader(path)
+        return r, int(r.fps_f), r.width, r.height
+    if magic == b"YUV4MPEG":
+        try:
+            r = Y4MReader(path)
+        except ValueError as e:
+            print(f"Error: {e}")
+            return None
         return r, int(r.fps_f), r.width, r.height
     if cv2 is not None:  # pragma: no cover
         cap = cv2.VideoCapture(path)
