@@ -241,6 +241,24 @@ def test_frames_at_and_below_the_smallest_pyramid(engine, oracle):
                 _check_cascade(eng, orc, fr)
 
 
+def test_random_shapes_match_oracle(engine, oracle):
+    """Seeded sweep over frame shapes (every byte phase of the row pitch, level sizes on both sides of the tile and pooling
+    edges, batches of 1-4): the whole cascade record and the embeddings equal the oracle's."""
+    rng = np.random.default_rng(20261004)
+    for t in range(24):
+        H, W, n = int(rng.integers(20, 260)), int(rng.integers(20, 340)), int(rng.integers(1, 5))
+        if t % 3 == 0:
+            fr = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+            if H * W > 120 * 160:                       # noise this large overflows the default candidate capacity (an error, tested elsewhere)
+                fr[:, :, :, :] = (fr // 8 + 112).astype(np.uint8)
+        else:
+            fr = truely_amd.synthetic.synthetic_frames(n, H, W, seed=1000 + t, faces=-1 if t % 3 == 2 else 1)
+        try:
+            _check_cascade(engine, oracle, fr)
+        except AssertionError as e:
+            raise AssertionError(f"case {t}: {n} x {H}x{W}: {e}") from e
+
+
 @pytest.mark.parametrize("variant", ["slopes_above_one", "negative_slopes"])
 def test_cascade_fused_pnet_prelu_variants(variant):
     """PReLU slopes outside [0, 1] take the generic kernel instantiation; a negative conv1 slope also forbids

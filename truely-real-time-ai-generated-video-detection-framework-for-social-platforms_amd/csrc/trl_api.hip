@@ -279,7 +279,10 @@ extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
 static int check_call(trl_ctx* c, const void* frames, int n, int H, int W) {
     if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
     if (!c->have_weights) { trl_set_error("trl_load_weights has not been called"); return TRL_ERR_STATE; }
-    if (!frames || n <= 0 || H < 12 || W < 12 || H > 16384 || W > 16384) { trl_set_error("bad frame batch n=%d H=%d W=%d", n, H, W); return TRL_ERR_INVALID; }
+    if (!frames || n <= 0 || n > 65535 || H < 12 || W < 12 || H > 16383 || W > 16383) {   // n: grid.y carries the frame index in several kernels
+        trl_set_error("bad frame batch n=%d H=%d W=%d (1..65535 frames of 12..16383 px per side)", n, H, W);
+        return TRL_ERR_INVALID;
+    }
     return TRL_OK;
 }
 
