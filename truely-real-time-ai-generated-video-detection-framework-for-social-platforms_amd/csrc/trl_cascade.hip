@@ -14,15 +14,16 @@
 #include "trl_ctx.h"
 #include <stdlib.h>
 
-// R-/O-Net candidates per launch set: one set covers a 256-frame batch (31 k / 8.5 k candidates), so no near-empty third chunk is
-// launched; scratch per chunk = 100 KB / 640 KB per candidate (5 / 8 GB at the cap, of 288 GB)
+// R-/O-Net candidates per launch set: one set covers a 256-frame batch's CAPACITY (160 / 48 candidates per frame + 64: 41 k / 12.4 k;
+// 31 k / 8.5 k are live), so no dead second chunk is launched (8 launches x 4.7 us); scratch per chunk = 100 KB / 640 KB per
+// candidate (5 / 10.7 GB at the cap, of 288 GB)
 static int env_chunk(const char* name, int dflt) {
     const char* e = getenv(name);
     const int v = e ? atoi(e) : 0;
     return v >= 16 ? v : dflt;
 }
 // (TRL_RNET_CHUNK / TRL_ONET_CHUNK shrink a launch set for tests, so that the multi-chunk path runs on small inputs)
-static const int TRL_CH2 = env_chunk("TRL_RNET_CHUNK", 49152), TRL_CH3 = env_chunk("TRL_ONET_CHUNK", 12288);
+static const int TRL_CH2 = env_chunk("TRL_RNET_CHUNK", 49152), TRL_CH3 = env_chunk("TRL_ONET_CHUNK", 16384);
 
 namespace {
 
