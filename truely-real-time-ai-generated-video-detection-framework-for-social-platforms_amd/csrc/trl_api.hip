@@ -558,31 +558,32 @@ int trl_debug_front_net(trl_ctx* c, const uint8_t* d_frame, int H, int W, const 
     TRL_HIP(hipSetDevice(c->cfg.device));
     const int capF = c->cfg.cap_frame;
     Arena& A = c->arena;
-    TRL_CHECK(trl_ensure(c, A, (size_t)capF * 20 + (size_t)capF * 8 + (1u << 20)));
+    TRL_CHECK(trl_ensure(c, A, (size_t)capF * 32 + (1u << 20)));
     A.reset();
     CascadeBufs& B = c->cb;
     B = CascadeBufs();
     B.n = 1; B.H = H; B.W = W;
-    float* boxes = (float*)A.alloc((size_t)capF * 20);
-    B.map_frame = (int32_t*)A.alloc((size_t)capF * 4); B.map_local = (int32_t*)A.alloc((size_t)capF * 4);
+    B.cbox = (int32_t*)A.alloc((size_t)capF * 32);
     int32_t* total = (int32_t*)A.alloc(64);
-    std::vector<float> hb((size_t)nb * 5, 0.f);
-    std::vector<int32_t> zeros(nb, 0), iota(nb);
-    for (int i = 0; i < nb; i++) { for (int q = 0; q < 4; q++) hb[5 * i + q] = h_boxes[4 * i + q]; iota[i] = i; }
-    TRL_HIP(hipMemcpyAsync(boxes, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, s));
-    TRL_HIP(hipMemcpyAsync(B.map_frame, zeros.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
-    TRL_HIP(hipMemcpyAsync(B.map_local, iota.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    std::vector<int32_t> hb((size_t)nb * 8, 0);        // the records k_build_map writes: frame 0, pad()'s clamped crop window
+    for (int i = 0; i < nb; i++) {
+        const float* b = h_boxes + 4 * i;
+        const int bx = (int)truncf(b[0]), by = (int)truncf(b[1]), bex = (int)truncf(b[2]), bey = (int)truncf(b[3]);
+        const int x = bx < 1 ? 1 : bx, y = by < 1 ? 1 : by, ex = bex > W ? W : bex, ey = bey > H ? H : bey;
+        hb[8 * i + 1] = y - 1; hb[8 * i + 2] = x - 1; hb[8 * i + 3] = ey - (y - 1); hb[8 * i + 4] = ex - (x - 1);
+    }
+    TRL_HIP(hipMemcpyAsync(B.cbox, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, s));
     TRL_HIP(hipMemcpyAsync(total, &nb, 4, hipMemcpyHostToDevice, s));
     TRL_HIP(hipStreamSynchronize(s));                      // the host vectors go out of scope
     c->scratch.reset();
     TRL_CHECK(trl_ensure(c, c->scratch, (size_t)nb * 700 * 1024 + (4u << 20)));
     if (net == 24) {
         float* pool1 = (float*)c->scratch.alloc((size_t)nb * 11 * 11 * 28 * 4);
-        TRL_CHECK(trl_launch_rnet_front(c, d_frame, H, W, boxes, total, 0, nb, pool1, s));
+        TRL_CHECK(trl_launch_rnet_front(c, d_frame, H, W, total, 0, nb, pool1, s));
         TRL_CHECK(trl_run_rnet_tail(c, pool1, nb, d_out, s, total, 0));
     } else {
         float* pool1 = (float*)c->scratch.alloc((size_t)nb * 23 * 23 * 32 * 4);
-        TRL_CHECK(trl_launch_onet_front(c, d_frame, H, W, boxes, total, 0, nb, pool1, s));
+        TRL_CHECK(trl_launch_onet_front(c, d_frame, H, W, total, 0, nb, pool1, s));
         TRL_CHECK(trl_run_onet_tail(c, pool1, nb, d_out, s, total, 0));
     }
     TRL_HIP(hipStreamSynchronize(s));

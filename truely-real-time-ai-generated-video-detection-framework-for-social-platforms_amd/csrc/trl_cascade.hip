@@ -321,11 +321,21 @@ __global__ __launch_bounds__(256) void k_scan_counts(const int32_t* __restrict__
     // the batch the next stage processes was sized by an optimistic capacity: report the real total and whether it fits
     if (threadIdx.x == 0) { flags[4 + slot] = sh[n]; if (sh[n] > cap_total) flags[2 + slot] = 1; }
 }
-__global__ void k_build_map(const int32_t* __restrict__ cnt, const int32_t* __restrict__ off, int32_t* __restrict__ map_frame,
-                            int32_t* __restrict__ map_local) {
+// Candidate list of a stage in launch order: candidate t = off[f] + i is box i of frame f.  The record holds what the front kernel
+// needs to start its crop -- frame index and pad()'s clamped window (detect_face.py pad(): x = max(x1, 1), ex = min(x2, W), crop
+// [y-1:ey, x-1:ex]) -- so that kernel reaches its first pixel load after ONE dependent read instead of three (map -> box -> pixels).
+__global__ void k_build_map(const int32_t* __restrict__ cnt, const int32_t* __restrict__ off, const float* __restrict__ boxes, int capF,
+                            int W, int H, int32_t* __restrict__ cbox) {
     const int f = blockIdx.x;
     const int c = cnt[f], o = off[f];
-    for (int i = threadIdx.x; i < c; i += blockDim.x) { map_frame[o + i] = f; map_local[o + i] = i; }
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+        const float* b = boxes + ((size_t)f * capF + i) * 5;
+        const int bx = (int)truncf(b[0]), by = (int)truncf(b[1]), bex = (int)truncf(b[2]), bey = (int)truncf(b[3]);
+        const int x = bx < 1 ? 1 : bx, y = by < 1 ? 1 : by, ex = bex > W ? W : bex, ey = bey > H ? H : bey;
+        int4* r = reinterpret_cast<int4*>(cbox + (size_t)(o + i) * 8);
+        r[0] = make_int4(f, y - 1, x - 1, ey - (y - 1));
+        r[1] = make_int4(ex - (x - 1), 0, 0, 0);
+    }
 }
 
 // ---- stage 2 tail: thr1, batched_nms(0.7), bbreg, rerec ------------------------------------------
@@ -700,7 +710,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     B.n = n; B.L = L; B.H = H; B.W = W;
     Arena& A = c->arena;      // cascade lists: live for the whole call (and for the debug hooks after it)
     Arena& X = c->scratch;    // activations: reset between stages
-    const size_t need = (size_t)n * L * ((size_t)cap * (sizeof(Cand) + 4) + 8) + (size_t)n * capF * (5 * 3 + 10 + 2) * 4 +
+    const size_t need = (size_t)n * L * ((size_t)cap * (sizeof(Cand) + 4) + 8) + (size_t)n * capF * (5 * 3 + 10 + 8) * 4 +
                         (size_t)n * 1024 + (1u << 20);   // + the API layer's per-frame outputs (box0, prob0, rect, valid, pts0)
     TRL_CHECK(trl_ensure(c, A, need));
     A.reset();
@@ -712,7 +722,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     B.s1_box = (float*)A.alloc((size_t)n * capF * 20); B.s2_box = (float*)A.alloc((size_t)n * capF * 20);
     B.s3_box = (float*)A.alloc((size_t)n * capF * 20); B.s3_pts = (float*)A.alloc((size_t)n * capF * 40);
     B.off2 = (int32_t*)A.alloc((size_t)(n + 1) * 4); B.off3 = (int32_t*)A.alloc((size_t)(n + 1) * 4);
-    B.map_frame = (int32_t*)A.alloc((size_t)n * capF * 4); B.map_local = (int32_t*)A.alloc((size_t)n * capF * 4);
+    B.cbox = (int32_t*)A.alloc((size_t)n * capF * 32);
     B.flags = (int32_t*)A.alloc(64);
     if (!B.flags) { trl_set_error("cascade workspace allocation failed"); return TRL_ERR_STATE; }
     TRL_HIP(hipMemsetAsync(B.flags, 0, 64, s));
@@ -820,7 +830,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     const int cap2 = c->cap_t2, cap3 = c->cap_t3;
     k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n1, n, B.off2, cap2, B.flags, 0);
     TRL_LAUNCH_CHECK();
-    k_build_map<<<n, 64, 0, s>>>(B.n1, B.off2, B.map_frame, B.map_local);
+    k_build_map<<<n, 64, 0, s>>>(B.n1, B.off2, B.s1_box, capF, W, H, B.cbox);
     TRL_LAUNCH_CHECK();
     X.reset();   // stream order keeps the PNet workspace alive until its kernels are done: reuse needs no host sync
     float* out6 = (float*)X.alloc((size_t)cap2 * 24);
@@ -832,7 +842,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
             X.off = mk;
             float* pool1 = (float*)X.alloc((size_t)nc * 11 * 11 * 28 * 4);
             if (!pool1 || !out6) { trl_set_error("rnet workspace"); return TRL_ERR_STATE; }
-            TRL_CHECK(trl_launch_rnet_front(c, d_frames, H, W, B.s1_box, B.off2 + n, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
+            TRL_CHECK(trl_launch_rnet_front(c, d_frames, H, W, B.off2 + n, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
             TRL_CHECK(trl_run_rnet_tail(c, pool1, nc, out6 + (size_t)t0 * 6, s, B.off2 + n, t0));
         }
     }
@@ -842,7 +852,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     // ---- stage 3: ONet --------------------------------------------------------------------------------
     k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n2, n, B.off3, cap3, B.flags, 1);
     TRL_LAUNCH_CHECK();
-    k_build_map<<<n, 64, 0, s>>>(B.n2, B.off3, B.map_frame, B.map_local);
+    k_build_map<<<n, 64, 0, s>>>(B.n2, B.off3, B.s2_box, capF, W, H, B.cbox);
     TRL_LAUNCH_CHECK();
     X.reset();
     float* out16 = (float*)X.alloc((size_t)cap3 * 64);
@@ -854,7 +864,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
             X.off = mk;
             float* pool1 = (float*)X.alloc((size_t)nc * 23 * 23 * 32 * 4);
             if (!pool1 || !out16) { trl_set_error("onet workspace"); return TRL_ERR_STATE; }
-            TRL_CHECK(trl_launch_onet_front(c, d_frames, H, W, B.s2_box, B.off3 + n, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
+            TRL_CHECK(trl_launch_onet_front(c, d_frames, H, W, B.off3 + n, t0, nc, pool1, s));   // crop + conv1 + pool1 in LDS
             TRL_CHECK(trl_run_onet_tail(c, pool1, nc, out16 + (size_t)t0 * 16, s, B.off3 + n, t0));
         }
     }

@@ -26,7 +26,7 @@ struct CascadeBufs {   // device pointers into the arena, valid until the next c
     int32_t* n3 = nullptr; float* s3_box = nullptr;   // [n], [n][cap_frame][5]
     float* s3_pts = nullptr;                           // [n][cap_frame][10]
     int32_t* off2 = nullptr; int32_t* off3 = nullptr; // [n+1] exclusive scans of n1 / n2
-    int32_t* map_frame = nullptr; int32_t* map_local = nullptr;  // [n*cap_frame]
+    int32_t* cbox = nullptr;     // [n*cap_frame][8]: candidate t of the current stage = {frame, y0, x0, ih, iw, 0, 0, 0} (pad()'s crop window)
     int32_t* flags = nullptr;        // [4]: overflow flags
 };
 
@@ -75,8 +75,8 @@ int trl_run_onet(trl_ctx* c, const float* d_crops, int n, float* d_out16, hipStr
 // n = CAPACITY of the launch; the candidates that exist are clamp(*n_dev - n_base, 0, n) (device-sized, no host sync)
 int trl_run_rnet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out6, hipStream_t s, const int32_t* n_dev = nullptr, int n_base = 0);
 int trl_run_onet_tail(trl_ctx* c, const float* d_pool1, int n, float* d_out16, hipStream_t s, const int32_t* n_dev = nullptr, int n_base = 0);
-int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, const int32_t* d_total, int t0, int nc, float* d_pool, hipStream_t s);
-int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, const int32_t* d_total, int t0, int nc, float* d_pool, hipStream_t s);
+int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const int32_t* d_total, int t0, int nc, float* d_pool, hipStream_t s);
+int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const int32_t* d_total, int t0, int nc, float* d_pool, hipStream_t s);
 // PNet on one materialised level for nf frames: heads [nf][oh][ow][6]
 int trl_run_pnet_generic(trl_ctx* c, const float* d_level, int nf, int h, int w, float* d_heads, hipStream_t s);
 size_t trl_pnet_generic_bytes(int nf, int h, int w);

@@ -13,14 +13,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ void pad_box(const float* b, int W, int H, int& y, int& ey, int& x, int& ex) {
-    const int bx = (int)truncf(b[0]), by = (int)truncf(b[1]), bex = (int)truncf(b[2]), bey = (int)truncf(b[3]);
-    x = bx < 1 ? 1 : bx;
-    y = by < 1 ? 1 : by;
-    ex = bex > W ? W : bex;
-    ey = bey > H ? H : bey;
-}
-
 typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at dword alignment
 
 __device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF for bytes b of the dword with rel+b < nbytes
@@ -33,9 +25,8 @@ __device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF
 //       2 = all slopes in [0, 1]: as 1, with prelu(v) == max(v, slope*v) (exact, one VALU op fewer).
 // The kernel is VALU-bound (crop unpacking, pooling), and VALU shares the FP32 pipe with the f32 MFMAs.
 template <int S, int C1, int R, int MODE>
-__global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__ frames, int nframes, int H, int W, int capF,
-                                                     const float* __restrict__ boxes, const int32_t* __restrict__ map_frame,
-                                                     const int32_t* __restrict__ map_local, const int32_t* __restrict__ d_total, int t0,
+__global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__ frames, int nframes, int H, int W,
+                                                     const int4* __restrict__ cbox, const int32_t* __restrict__ d_total, int t0,
                                                      const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ s1,
                                                      float* __restrict__ out, int dbg_skip) {
@@ -58,17 +49,21 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int t = t0 + blockIdx.x;
-    if (t >= *d_total) return;          // the launch is sized by a capacity; candidates past the device-side total do not exist
+    // The candidate record and the device-side total are requested together: ONE memory round trip between the launch and the
+    // crop's pixel loads (the crop is bound by dependent round trips).  Records past the total are unwritten memory inside the
+    // list's allocation; they are read and discarded.
+    const int4 cb0 = cbox[2 * (size_t)t], cb1 = cbox[2 * (size_t)t + 1];
+    const int total = *d_total;
+    asm volatile("" ::"s"(cb0.x), "s"(cb1.x), "s"(total));   // both scalar loads are issued before the branch below (hipcc would sink the record's load behind it)
+    if (t >= total) return;             // the launch is sized by a capacity; candidates past the device-side total do not exist
 
     // ---- crop + area resample + normalise -> in_s [S][S][3] ----------------------------------------------
     // Each WAVE owns output rows oy = wave, wave+4, ...: (1) column sums of the bin's source rows, lanes along
     // the row (coalesced aligned dwords re-aligned with v_alignbyte, four byte-columns per lane) into a
     // per-wave LDS strip, (2) horizontal bins from the strip.  Integer sums: exact in any order.  No block barrier.
     {
-        const int f = map_frame[t], i = map_local[t];
-        int y, ey, x, ex;
-        pad_box(boxes + ((size_t)f * capF + i) * 5, W, H, y, ey, x, ex);
-        const int y0 = y - 1, x0 = x - 1, ih = ey - y0, iw = ex - x0;
+        const int f = __builtin_amdgcn_readfirstlane(cb0.x), y0 = __builtin_amdgcn_readfirstlane(cb0.y), x0 = __builtin_amdgcn_readfirstlane(cb0.z);
+        const int ih = __builtin_amdgcn_readfirstlane(cb0.w), iw = __builtin_amdgcn_readfirstlane(cb1.x);
         const uint32_t* base32 = reinterpret_cast<const uint32_t*>(frames);
         const long long last_dw = ((long long)nframes * H * W * 3 - 1) >> 2;   // last dword holding frame bytes
         const long long fbyte0 = (long long)f * H * W * 3;
@@ -363,7 +358,7 @@ int slope_mode(const DevV* sl, int n) {
 static int front_dbg() { static const int v = getenv("TRL_FRONT_SKIP") ? atoi(getenv("TRL_FRONT_SKIP")) : 0; return v; }
 
 // R-Net front: pooled [nc][11][11][28]
-int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, const int32_t* d_total, int t0, int nc,
+int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const int32_t* d_total, int t0, int nc,
                           float* d_pool, hipStream_t s) {
     if (nc <= 0) return TRL_OK;
     const DevW* w = trl_w(c, "rnet.conv1.w");
@@ -371,8 +366,8 @@ int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("rnet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->rnet_front_mode < 0) c->rnet_front_mode = slope_mode(sl, 28);
     static const int rr = getenv("TRL_RNET_R") ? atoi(getenv("TRL_RNET_R")) : 4;     // tuning aid: pooled rows per conv1 strip
-#define TRL_RF(RR, MODE) k_mtcnn_front<24, 28, RR, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
-                                                                       c->cb.map_local, d_total, t0, w->p, b->p, sl->p, d_pool, front_dbg() & 3)
+#define TRL_RF(RR, MODE) k_mtcnn_front<24, 28, RR, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, reinterpret_cast<const int4*>(c->cb.cbox), \
+                                                                       d_total, t0, w->p, b->p, sl->p, d_pool, front_dbg() & 3)
     if (c->rnet_front_mode == 2) { if (rr == 2) TRL_RF(2, 2); else if (rr == 3) TRL_RF(3, 2); else if (rr == 6) TRL_RF(6, 2); else TRL_RF(4, 2); }
     else if (c->rnet_front_mode == 1) TRL_RF(4, 1); else TRL_RF(4, 0);
 #undef TRL_RF
@@ -380,7 +375,7 @@ int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     return TRL_OK;
 }
 // O-Net front: pooled [nc][23][23][32]
-int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const float* boxes, const int32_t* d_total, int t0, int nc,
+int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const int32_t* d_total, int t0, int nc,
                           float* d_pool, hipStream_t s) {
     if (nc <= 0) return TRL_OK;
     const DevW* w = trl_w(c, "onet.conv1.w");
@@ -389,8 +384,8 @@ int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     if (c->onet_front_mode < 0) c->onet_front_mode = slope_mode(sl, 32);
     static const int orr = getenv("TRL_ONET_R") ? atoi(getenv("TRL_ONET_R")) : 1;   // measured: one pooled row per strip = 49 KB of LDS = three resident
                                                                                    // workgroups per CU: 1.18 vs 1.27 ms (R = 3, two per CU) for the O-Net front
-#define TRL_OF(RR, MODE) k_mtcnn_front<48, 32, RR, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, c->cfg.cap_frame, boxes, c->cb.map_frame, \
-                                                                       c->cb.map_local, d_total, t0, w->p, b->p, sl->p, d_pool, (front_dbg() >> 2) & 3)
+#define TRL_OF(RR, MODE) k_mtcnn_front<48, 32, RR, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, reinterpret_cast<const int4*>(c->cb.cbox), \
+                                                                       d_total, t0, w->p, b->p, sl->p, d_pool, (front_dbg() >> 2) & 3)
     if (c->onet_front_mode == 2) { if (orr == 3) TRL_OF(3, 2); else if (orr == 2) TRL_OF(2, 2); else if (orr == 4) TRL_OF(4, 2); else TRL_OF(1, 2); }
     else if (c->onet_front_mode == 1) TRL_OF(1, 1); else TRL_OF(1, 0);
 #undef TRL_OF
