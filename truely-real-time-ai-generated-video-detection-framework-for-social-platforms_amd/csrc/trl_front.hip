@@ -7,11 +7,19 @@
 // weights in registers, k ascending from the bias: bit-identical to the oracle's conv2d chain.
 #include "trl_ctx.h"
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// a / b for b's correctly rounded reciprocal r: the correctly rounded quotient on the verified domain (see the reduce step below)
+__device__ __forceinline__ float rdiv(float a, float b, float r) {
+    const float q0 = a * r;
+    const float e = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(e, r, q0);
+}
 
 typedef unsigned u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at dword alignment
 
@@ -140,6 +148,11 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
             unsigned* colA = colbuf;
             unsigned* colB = colbuf + CAP2;
             const long long row_pitch = (long long)W * 3;
+            const bool same_phase = (row_pitch & 3) == 0;
+            // adaptive-pool bins [floor(i a), ceil((i+1) a)), a = iw / S, are ceil(a) or ceil(a) + 1 columns wide
+            const int kwA0 = (iw + S - 1) / S;
+            const float rkw0 = 1.0f / (float)kwA0, rkw1 = 1.0f / (float)(kwA0 + 1);
+            const bool fastdiv = ih <= 94 * S && iw <= 94 * S;      // every bin <= 96 x 96: the verified domain of rdiv
             for (int oyA = wave; oyA < S; oyA += 8) {
                 const int oyB = oyA + 4;
                 const int ysA = (oyA * ih) / S, yeA = ((oyA + 1) * ih + S - 1) / S, khA = yeA - ysA;
@@ -155,83 +168,115 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                     const int seg_bytes = (xeb - xsa) * 3;
                     const long long o_segA = fbyte0 + ((long long)(y0 + ysA) * W + x0 + xsa) * 3;
                     const long long o_segB = fbyte0 + ((long long)(y0 + ysB) * W + x0 + xsa) * 3;
-                    for (int c0 = 0; c0 < seg_bytes; c0 += 4 * 252) {
+                    // Column sums of the segment's source bytes over the bin's rows, one 32-bit accumulator per byte column and
+                    // bin (v_dot4 with a one-hot byte weight: acc += byte j; a row only the other bin has gets weight 0).  This
+                    // path is bound by its VALU instructions, so (a) only the chunks the segment reaches are processed (one
+                    // straight-line instantiation per chunk count: guards inside the unrolled body made hipcc wait for the loads
+                    // chunk by chunk), (b) when the row pitch is a multiple of 4 every row of the box has the SAME byte phase, so
+                    // the dwords are summed as loaded (aligned columns, 64 payload dwords per chunk) and the phase is applied once,
+                    // as an index shift at the flush -- 4 VALU per dword instead of 8; other pitches re-align every dword first
+                    // (lane i takes dword i+1 from lane i+1 by a DPP wave shift; lane 63 only feeds lane 62: 63 payload dwords).
+                    const int sh0 = same_phase ? (int)(o_segA & 3) : 0;              // byte phase of the segment start
+                    const int cstride = same_phase ? 256 : 252;                      // payload bytes per chunk
+                    const int span = seg_bytes + sh0;                                // aligned-relative bytes to cover
+                    for (int c0 = 0; c0 < span; c0 += 4 * cstride) {
+                        const int rem = span - c0;
+                        const int nch = 1 + (rem > cstride ? 1 : 0) + (rem > 2 * cstride ? 1 : 0) + (rem > 3 * cstride ? 1 : 0);   // uniform
                         unsigned sum[2][4][4];
 #pragma unroll
                         for (int z = 0; z < 2; z++)
 #pragma unroll
                             for (int c = 0; c < 4; c++) { sum[z][c][0] = 0; sum[z][c][1] = 0; sum[z][c][2] = 0; sum[z][c][3] = 0; }
-                        for (int yb = 0; yb < khm; yb += 256) {
-                            const int yl = (khm - yb) < 256 ? (khm - yb) : 256;
-                            unsigned ev[2][4], od[2][4];                 // bytes 0,2 / 1,3 of each dword column
+                        // One step = 4 source rows of both bins x NCH chunks, all loads in flight together.  (More rows per step for
+                        // narrow segments -- 16 x 1 chunk, 8 x 2 -- was measured and is slower: dead rows still cost their loads.)
+                        auto step = [&](auto NCH_T, auto PHASE_T, int yy) {
+                            constexpr int NCH = decltype(NCH_T)::value;
+                            constexpr int RS = 4;
+                            constexpr bool PH = decltype(PHASE_T)::value;
+                            unsigned lo[2][RS][NCH];
+                            unsigned shr[2][RS];
 #pragma unroll
                             for (int z = 0; z < 2; z++)
 #pragma unroll
-                                for (int c = 0; c < 4; c++) { ev[z][c] = 0; od[z][c] = 0; }
-                            for (int yy = 0; yy < yl; yy += 4) {
-                                unsigned lo[2][4][4];
-                                unsigned shr[2][4];
+                                for (int r = 0; r < RS; r++) {
+                                    const int kh_z = z ? khB : khA;
+                                    const int rr = (yy + r < kh_z) ? yy + r : 0;                          // dead rows re-read row 0 (weight 0)
+                                    const long long o = (z ? o_segB : o_segA) + (long long)rr * row_pitch - sh0 + c0;   // scalar
+                                    const long long dw = o >> 2;
+                                    shr[z][r] = (unsigned)(o & 3);
+                                    const long long room = last_dw - dw;                             // >= 0: byte o is a frame byte
+                                    const unsigned lim = room > 0x3fffffll ? 0xfffffcu : (unsigned)room * 4u;
+                                    const char* rowp = reinterpret_cast<const char*>(base32 + dw);
 #pragma unroll
-                                for (int z = 0; z < 2; z++)
-#pragma unroll
-                                    for (int r = 0; r < 4; r++) {
-                                        const int kh_z = z ? khB : khA;
-                                        const int rr = (yb + yy + r < kh_z) ? yb + yy + r : 0;              // dead rows re-read row 0
-                                        const long long o = (z ? o_segB : o_segA) + (long long)rr * row_pitch + c0;   // scalar
-                                        const long long dw = o >> 2;
-                                        shr[z][r] = (unsigned)(o & 3);
-                                        const long long room = last_dw - dw;                             // >= 0: byte o is a frame byte
-                                        const unsigned lim = room > 0x3fffffll ? 0xfffffcu : (unsigned)room * 4u;
-                                        const char* rowp = reinterpret_cast<const char*>(base32 + dw);
-#pragma unroll
-                                        for (int c = 0; c < 4; c++) {
-                                            const unsigned ob = 252u * c + 4u * lane;
-                                            lo[z][r][c] = *reinterpret_cast<const uint32_t*>(rowp + (ob < lim ? ob : lim));
-                                        }
+                                    for (int c = 0; c < NCH; c++) {
+                                        const unsigned ob = (PH ? 256u : 252u) * c + 4u * lane;
+                                        lo[z][r][c] = *reinterpret_cast<const uint32_t*>(rowp + (ob < lim ? ob : lim));
                                     }
-#pragma unroll
-                                for (int z = 0; z < 2; z++)
-#pragma unroll
-                                    for (int r = 0; r < 4; r++) {
-                                        const bool live = yb + yy + r < (z ? khB : khA);
-#pragma unroll
-                                        for (int c = 0; c < 4; c++) {
-                                            const unsigned l = lo[z][r][c];
-                                            const unsigned h = (unsigned)__builtin_amdgcn_update_dpp((int)l, (int)l, 0x130, 0xF, 0xF, false);   // wave_shl:1
-                                            unsigned v = __builtin_amdgcn_alignbyte(h, l, shr[z][r]);
-                                            v = live ? v : 0u;
-                                            ev[z][c] += v & 0x00FF00FFu;
-                                            od[z][c] += (v >> 8) & 0x00FF00FFu;
-                                        }
-                                    }
-                            }
-#pragma unroll
-                            for (int z = 0; z < 2; z++)
-#pragma unroll
-                                for (int c = 0; c < 4; c++) {
-                                    sum[z][c][0] += ev[z][c] & 0xFFFFu; sum[z][c][2] += ev[z][c] >> 16;
-                                    sum[z][c][1] += od[z][c] & 0xFFFFu; sum[z][c][3] += od[z][c] >> 16;
                                 }
-                        }
+#pragma unroll
+                            for (int z = 0; z < 2; z++)
+#pragma unroll
+                                for (int r = 0; r < RS; r++) {
+                                    const unsigned w0 = (yy + r < (z ? khB : khA)) ? 1u : 0u;        // scalar: 0 for a row this bin lacks
+#pragma unroll
+                                    for (int c = 0; c < NCH; c++) {
+                                        unsigned v = lo[z][r][c];
+                                        if (!PH) {
+                                            const unsigned h = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false);   // wave_shl:1
+                                            v = __builtin_amdgcn_alignbyte(h, v, shr[z][r]);
+                                        }
+                                        sum[z][c][0] = __builtin_amdgcn_udot4(v, w0, sum[z][c][0], false);
+                                        sum[z][c][1] = __builtin_amdgcn_udot4(v, w0 << 8, sum[z][c][1], false);
+                                        sum[z][c][2] = __builtin_amdgcn_udot4(v, w0 << 16, sum[z][c][2], false);
+                                        sum[z][c][3] = __builtin_amdgcn_udot4(v, w0 << 24, sum[z][c][3], false);
+                                    }
+                                }
+                        };
+                        auto rows = [&](auto NCH_T) {
+                            constexpr int RS = 4;
+                            if (same_phase) { for (int yy = 0; yy < khm; yy += RS) step(NCH_T, std::true_type{}, yy); }
+                            else { for (int yy = 0; yy < khm; yy += RS) step(NCH_T, std::false_type{}, yy); }
+                        };
+                        if (nch == 1) rows(std::integral_constant<int, 1>{});
+                        else if (nch == 2) rows(std::integral_constant<int, 2>{});
+                        else if (nch == 3) rows(std::integral_constant<int, 3>{});
+                        else rows(std::integral_constant<int, 4>{});
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
-                            const int b = c0 + 252 * c + 4 * lane;
-                            if (lane < 63 && b < seg_bytes) {
-                                colA[b] = sum[0][c][0]; colA[b + 1] = sum[0][c][1]; colA[b + 2] = sum[0][c][2]; colA[b + 3] = sum[0][c][3];
-                                colB[b] = sum[1][c][0]; colB[b + 1] = sum[1][c][1]; colB[b + 2] = sum[1][c][2]; colB[b + 3] = sum[1][c][3];
+                            if (c < nch) {
+                                const int b = c0 + cstride * c + 4 * lane - sh0;     // segment byte of this lane's byte 0
+                                if (same_phase || lane < 63) {
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) {
+                                        if (b + j >= 0 && b + j < seg_bytes) { colA[b + j] = sum[0][c][j]; colB[b + j] = sum[1][c][j]; }
+                                    }
+                                }
                             }
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
+                    // bin means: the exhaustively verified reciprocal division (two fmas per division, pyr_div in trl_pnet.hip's terms;
+                    // oracle/trl_oracle.c orc_selftest_recip_div: equal to a / kh / kw for every bin <= 96 x 96 and every byte sum)
                     const float fkhA = (float)khA, fkhB = (float)khB;
+                    const float rkhA = 1.0f / fkhA, rkhB = 1.0f / fkhB;
                     for (int idx = lane; idx < (oxb - oxa) * 3; idx += 64) {
                         const int ox = oxa + idx / 3, c = idx % 3;
                         const int xs = (ox * iw) / S, xe = ((ox + 1) * iw + S - 1) / S;
                         unsigned accA = 0, accB = 0;
                         for (int xx = xs; xx < xe; xx++) { accA += colA[(xx - xsa) * 3 + c]; accB += colB[(xx - xsa) * 3 + c]; }
-                        const float fkw = (float)(xe - xs);
-                        in_s[(oyA * S + ox) * 3 + c] = ((float)accA / fkhA / fkw - 127.5f) * 0.0078125f;
-                        in_s[(oyB * S + ox) * 3 + c] = ((float)accB / fkhB / fkw - 127.5f) * 0.0078125f;
+                        const int kw = xe - xs;
+                        const float fkw = (float)kw;
+                        float qA, qB;
+                        if (fastdiv && (kw == kwA0 || kw == kwA0 + 1)) {
+                            const float rkw = kw == kwA0 ? rkw0 : rkw1;
+                            qA = rdiv(rdiv((float)accA, fkhA, rkhA), fkw, rkw);
+                            qB = rdiv(rdiv((float)accB, fkhB, rkhB), fkw, rkw);
+                        } else {
+                            qA = (float)accA / fkhA / fkw;
+                            qB = (float)accB / fkhB / fkw;
+                        }
+                        in_s[(oyA * S + ox) * 3 + c] = (qA - 127.5f) * 0.0078125f;
+                        in_s[(oyB * S + ox) * 3 + c] = (qB - 127.5f) * 0.0078125f;
                     }
                     __builtin_amdgcn_wave_barrier();
                     oxa = oxb;
