@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                     // segment of output columns whose source span fits half the strip
                     const int xsa = (oxa * iw) / S;
                     int oxb = oxa + 1;
-                    while (oxb < S && (((oxb + 1) * iw + S - 1) / S - xsa) * 3 <= CAP2 - 4) oxb++;
+                    if ((iw - xsa) * 3 <= CAP2 - 4) oxb = S;      // the rest of the row fits (every box up to ~300 px): no search
+                    else while (oxb < S && (((oxb + 1) * iw + S - 1) / S - xsa) * 3 <= CAP2 - 4) oxb++;
                     const int xeb = (oxb * iw + S - 1) / S;
                     const int seg_bytes = (xeb - xsa) * 3;
                     const long long o_segA = fbyte0 + ((long long)(y0 + ysA) * W + x0 + xsa) * 3;
@@ -189,10 +190,12 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                             for (int c = 0; c < 4; c++) { sum[z][c][0] = 0; sum[z][c][1] = 0; sum[z][c][2] = 0; sum[z][c][3] = 0; }
                         // One step = 4 source rows of both bins x NCH chunks, all loads in flight together.  (More rows per step for
                         // narrow segments -- 16 x 1 chunk, 8 x 2 -- was measured and is slower: dead rows still cost their loads.)
-                        auto step = [&](auto NCH_T, auto PHASE_T, int yy) {
+                        // SAFE: no byte any lane of this pass can touch lies past the frame buffer (true except for boxes at the very
+                        // end of the last frame), so a load is a scalar row base + the lane's constant offset: no clamp, no VALU.
+                        auto step = [&](auto NCH_T, auto PHASE_T, auto SAFE_T, int yy) {
                             constexpr int NCH = decltype(NCH_T)::value;
                             constexpr int RS = 4;
-                            constexpr bool PH = decltype(PHASE_T)::value;
+                            constexpr bool PH = decltype(PHASE_T)::value, SAFE = decltype(SAFE_T)::value;
                             unsigned lo[2][RS][NCH];
                             unsigned shr[2][RS];
 #pragma unroll
@@ -202,15 +205,20 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                                     const int kh_z = z ? khB : khA;
                                     const int rr = (yy + r < kh_z) ? yy + r : 0;                          // dead rows re-read row 0 (weight 0)
                                     const long long o = (z ? o_segB : o_segA) + (long long)rr * row_pitch - sh0 + c0;   // scalar
-                                    const long long dw = o >> 2;
                                     shr[z][r] = (unsigned)(o & 3);
-                                    const long long room = last_dw - dw;                             // >= 0: byte o is a frame byte
-                                    const unsigned lim = room > 0x3fffffll ? 0xfffffcu : (unsigned)room * 4u;
-                                    const char* rowp = reinterpret_cast<const char*>(base32 + dw);
+                                    const char* rowp = reinterpret_cast<const char*>(frames) + (PH ? o : (o & ~3ll));
+                                    if (SAFE) {
 #pragma unroll
-                                    for (int c = 0; c < NCH; c++) {
-                                        const unsigned ob = (PH ? 256u : 252u) * c + 4u * lane;
-                                        lo[z][r][c] = *reinterpret_cast<const uint32_t*>(rowp + (ob < lim ? ob : lim));
+                                        for (int c = 0; c < NCH; c++)
+                                            lo[z][r][c] = *reinterpret_cast<const uint32_t*>(rowp + (PH ? 256 : 252) * c + 4 * lane);
+                                    } else {
+                                        const long long room = last_dw - (o >> 2);                       // >= 0: byte o is a frame byte
+                                        const unsigned lim = room > 0x3fffffll ? 0xfffffcu : (unsigned)room * 4u;
+#pragma unroll
+                                        for (int c = 0; c < NCH; c++) {
+                                            const unsigned ob = (PH ? 256u : 252u) * c + 4u * lane;
+                                            lo[z][r][c] = *reinterpret_cast<const uint32_t*>(rowp + (ob < lim ? ob : lim));
+                                        }
                                     }
                                 }
 #pragma unroll
@@ -232,15 +240,18 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                                     }
                                 }
                         };
-                        auto rows = [&](auto NCH_T) {
+                        auto rows = [&](auto NCH_T, auto SAFE_T) {
                             constexpr int RS = 4;
-                            if (same_phase) { for (int yy = 0; yy < khm; yy += RS) step(NCH_T, std::true_type{}, yy); }
-                            else { for (int yy = 0; yy < khm; yy += RS) step(NCH_T, std::false_type{}, yy); }
+                            if (same_phase) { for (int yy = 0; yy < khm; yy += RS) step(NCH_T, std::true_type{}, SAFE_T, yy); }
+                            else { for (int yy = 0; yy < khm; yy += RS) step(NCH_T, std::false_type{}, SAFE_T, yy); }
                         };
-                        if (nch == 1) rows(std::integral_constant<int, 1>{});
-                        else if (nch == 2) rows(std::integral_constant<int, 2>{});
-                        else if (nch == 3) rows(std::integral_constant<int, 3>{});
-                        else rows(std::integral_constant<int, 4>{});
+                        // furthest byte of the pass: bin B's last row (oyB > oyA and bin edges are monotone, so yeB >= yeA), last chunk, lane 63
+                        const long long o_far = o_segB + (long long)(khB - 1) * row_pitch - sh0 + c0 + (long long)(nch - 1) * cstride + 255;
+                        if ((o_far >> 2) > last_dw) rows(std::integral_constant<int, 4>{}, std::false_type{});   // clamped loads
+                        else if (nch == 1) rows(std::integral_constant<int, 1>{}, std::true_type{});
+                        else if (nch == 2) rows(std::integral_constant<int, 2>{}, std::true_type{});
+                        else if (nch == 3) rows(std::integral_constant<int, 3>{}, std::true_type{});
+                        else rows(std::integral_constant<int, 4>{}, std::true_type{});
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             if (c < nch) {
