@@ -160,6 +160,11 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    # stdout carries exactly ONE line, rank 0's JSON: everything else a rank or a library prints there (gloo announces its
+    # connections on stdout from C++) goes to stderr instead -- the launcher forwards every rank's stdout to the caller.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -380,7 +385,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(frames_np, threads, cfg)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,8 +24,8 @@ def _bench(*flags, timeout=600):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout,
                        env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]          # rank 0 prints ONE JSON line
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]   # stdout is ONE JSON line (rank 0's), nothing else
     return json.loads(lines[0])
 
 
