@@ -83,6 +83,20 @@ struct Arena {
 };
 
 #ifdef __HIPCC__
+// max without the compiler's operand canonicalisation: with IEEE mode on, hipcc quiets possible signalling NaNs in front of a
+// two-operand v_max_f32 whose inputs it cannot prove canonical (values out of an MFMA or a load: one extra v_max_f32 x, x, x per
+// operand).  The data here is finite, and in kernels that share the FP32 pipe with f32 MFMAs every VALU instruction costs
+// matrix throughput.
+__device__ __forceinline__ float vmax_nc(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3_nc(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int trl_live_rows(const ConvArgs& a) {   // rows of the GEMM that exist (uniform: scalar loads)
     if (!a.m_dev) return a.M;
     int t = *a.m_dev - a.m_base;

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
     __syncthreads();
 
     float* dst = out + (size_t)blockIdx.x * P * P * C1;
-    auto act = [&](float v, float sl) { return MODE == 2 ? fmaxf(v, sl * v) : (v > 0.f ? v : sl * v); };
+    auto act = [&](float v, float sl) { return MODE == 2 ? vmax_nc(v, sl * v) : (v > 0.f ? v : sl * v); };
     float* const erow = c1_s + (kq * 4) * CLD + l15;             // epilogue lane base: row 4*kq (+q), channel l15
     if (dbg_skip & 2) return;
     for (int p0 = 0; p0 < P; p0 += R) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
                     if (dy == 0 && dx == 0) continue;
                     if (dx == 2 && !x2) continue;
                     const float4 v = *reinterpret_cast<const float4*>(src + (dy * CW + dx) * CLD);
-                    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+                    best.x = vmax_nc(best.x, v.x); best.y = vmax_nc(best.y, v.y); best.z = vmax_nc(best.z, v.z); best.w = vmax_nc(best.w, v.w);
                 }
             }
             if (MODE != 0) {

@@ -379,8 +379,9 @@ __device__ __forceinline__ int koff(int s, int kq, int e1, int e2, int e3) {
 
 // UNIT: every PReLU slope of the net lies in [0, 1]; then prelu(v) == max(v, slope*v) exactly (two VALU ops instead
 // of three) and max-pool commutes with PReLU.  Any other weights take the generic instantiation.
+// (vmax_nc / vmax3_nc: trl_common.h)
 template <bool UNIT>
-__device__ __forceinline__ float prelu_t(float v, float sl) { return UNIT ? fmaxf(v, sl * v) : prelu(v, sl); }
+__device__ __forceinline__ float prelu_t(float v, float sl) { return UNIT ? vmax_nc(v, sl * v) : prelu(v, sl); }
 
 // CLK: diagnostic instantiation that records the launch's execution span on the device wall clock (TRL_PNET_CLOCK=1);
 // the production instantiation carries no instrumentation.
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     const float bias2 = a.b2[l15], slope2 = a.s2[l15];
     const float bias3 = a.b3[l31], slope3 = a.s3[l31];
     const float biash = a.bh[l15];
+    const f32x4 bias1v = {bias1, bias1, bias1, bias1}, bias2v = {bias2, bias2, bias2, bias2}, biashv = {biash, biash, biash, biash};
 
     // LDS beyond the live tiles is read by zero-weight k padding: it must hold finite values
     for (int i = tid; i < REGION_A; i += 256) RA[i] = 0.f;
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     const bool r0 = 2 * py < vy, r1 = 2 * py + 1 < vy;
                     const bool c0 = 8 * pg + 2 * kq < vx, c1 = 8 * pg + 2 * kq + 1 < vx;
                     if (kMode == 2) {
-                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        const float m = vmax_nc(vmax3_nc(v[0], v[1], v[2]), v[3]);
                         outv = prelu_t<UNIT>(m, slope1);
                     } else if (kMode == 1) {                          // ceil-mode window clipped by the level edge
                         const float ninf = -__builtin_inff();
@@ -576,10 +578,12 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                         if (2 * jp + 3 < 25) read_tile(2 * jp + 3, xs[cb ^ 1] + 7);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[cb][0] = f32x4{bias1, bias1, bias1, bias1};
-                    acc[cb][1] = acc[cb][0];
+                    // the chain starts from the bias: the first MFMA reads the (never overwritten) bias quad as its C operand
+                    // and writes the accumulator -- no per-tile copies of the bias into the accumulator registers
+                    acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][0], B1[0], bias1v, 0, 0, 0);
+                    if (jp < 12) acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][7], B1[0], bias1v, 0, 0, 0);
 #pragma unroll
-                    for (int s = 0; s < 7; s++) {
+                    for (int s = 1; s < 7; s++) {
                         acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][s], B1[s], acc[cb][0], 0, 0, 0);
                         if (jp < 12) acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][7 + s], B1[s], acc[cb][1], 0, 0, 0);
                     }
@@ -626,18 +630,21 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 // read are skipped (M-tile m covers cells 16m.. of the 18-wide grid).  Uniform per wave, no barrier inside.
                 const bool hasB = mtB < 21 && 16 * mtB < lim2;  // j == 2: only wave role 0 has a second tile (M-tile 20)
                 const bool hasA = 16 * mtA < lim2;
-                f32x4 accA = {bias2, bias2, bias2, bias2}, accB = accA;
+                f32x4 accA = bias2v, accB = bias2v;
                 __builtin_amdgcn_sched_barrier(0);
                 if (!hasA) {
                 } else if (hasB) {
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0], B2[0], bias2v, 0, 0, 0);     // C operand = the bias quad (see conv1)
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[0], B2[0], bias2v, 0, 0, 0);
 #pragma unroll
-                    for (int s = 0; s < 23; s++) {
+                    for (int s = 1; s < 23; s++) {
                         accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
                         accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B2[s], accB, 0, 0, 0);
                     }
                 } else {
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0], B2[0], bias2v, 0, 0, 0);
 #pragma unroll
-                    for (int s = 0; s < 23; s++) accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
+                    for (int s = 1; s < 23; s++) accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 2) read_pair2(j + 1);
@@ -698,13 +705,13 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 }
                 __builtin_amdgcn_wave_barrier();
                 // heads: two 16-row M-tiles, K = 32
-                f32x4 hA = {biash, biash, biash, biash}, hB = hA;
+                f32x4 hA, hB;
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
                     const float xa = ST[l15 * ST_LD + 4 * s + kq];
                     const float xb = ST[(16 + l15) * ST_LD + 4 * s + kq];
-                    hA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, BH[s], hA, 0, 0, 0);
-                    hB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, BH[s], hB, 0, 0, 0);
+                    hA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, BH[s], s == 0 ? biashv : hA, 0, 0, 0);
+                    hB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, BH[s], s == 0 ? biashv : hB, 0, 0, 0);
                 }
                 // lane (n = l15, rows kq*4+q): n=0,1 class logits, n=2..5 box regression -> [row][9] staging
                 if (l15 < 6) {
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     if (oy < g.oh && ox < g.ow) {
                         const float* hv = HS + lane * 9;
                         const float p = trl_softmax2_p1(hv[0], hv[1]);
-                        if (p >= a.thr) {
+                        if (p >= a.thr && !(a.dbg_skip & 32)) {      // (bit 32: timing-only ablations emit no candidates)
                             const int seg = f * a.L + l;
                             const int sl = atomicAdd(&a.lvl_cnt[seg], 1);
                             if (sl < a.cap) {
