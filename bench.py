@@ -13,9 +13,12 @@ as a child, BEFORE anything here touches the GPU -- and exits with the child's c
   --mode streams          : BASELINE configs[3] -- one independent clip per GPU, no data-path collective.
   --config {0,1,2,4}      : which BASELINE.json configs[] entry the workload is (1 = headline, default).
   --ingest nv12           : supplementary leg: host NV12 -> pinned H2D -> BGR on the device -> the same path.
-  --embed-group G         : supplementary: each worker embeds the faces of G of its steps in ONE InceptionResnetV1 call (default 1 = per
-                            step; results are bit-identical for any G -- the embedder's ~100 small launches amortise over more faces, but on
-                            runs of 10-20 steps the pipeline's longer fill and drain cancel the gain).
+  --embed-group G         : the decoupled embedder embeds the crops of G consecutive steps in ONE InceptionResnetV1 call on its own context
+                            and stream (default 3 = 768 faces per call; 1 = inside each step's call).  Results are bit-identical for any
+                            G: the embedder's ~100 small dependent launches amortise over more faces (2.22 ms per 256 faces at 256 per
+                            call, 1.78 ms = 42.7 % of the f32-MFMA peak at 768).
+  --driver single|threads : ONE host thread drives every context through trl_detect_embed_begin / _end (default), or one blocking
+                            host thread per context (round 2's scheme; --embed-group then groups per worker).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -81,21 +84,44 @@ def make_clip(cfg, n, seed):
     return out
 
 
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def host_cores():
+    """Cores this process may use: the scheduler affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(frames_np, threads, cfg):
-    """Restated reference CPU path (oracle/torch_ref.py: torch CPU fp32, ONE frame at a time exactly
-    as server/model.py:42-59 drives facenet-pytorch), on a bounded sample of the same workload."""
+    """Restated reference CPU path (oracle/torch_ref.py: torch CPU fp32) on a bounded sample of the same workload, on ALL the
+    host cores this process may use.  Two figures: `value` = ONE frame at a time exactly as
+    server/model.py:42-59 drives facenet-pytorch; `batched` = the same restatement with the frames spread over the cores (one
+    single-threaded frame pipeline per core -- the CPU's best case for this workload: no cross-thread synchronisation inside the
+    small PNet / R-Net convolutions)."""
+    import torch
     import truely_amd
     from oracle.torch_ref import TorchRef
     from oracle.oracle import Oracle
     H, W = cfg["H"], cfg["W"]
     sds = truely_amd.weights.synthetic_state_dicts(0)
-    ref = TorchRef(*sds, threads=threads, min_face_size=cfg["min_face"])
     orc = Oracle(truely_amd.weights.pack_state_dicts(*sds))
-    t0 = time.time()
-    done = 0
-    budget = float(os.environ.get("TRUELY_CPU_BASELINE_SECONDS", "20"))
-    while time.time() - t0 < budget:
-        fr = frames_np[done % len(frames_np)]
+    budget = float(os.environ.get("TRUELY_CPU_BASELINE_SECONDS", "12"))
+
+    def one_frame(ref, fr):
         boxes, _ = ref.detect(fr)
         if boxes is not None and len(boxes) > 0:
             b = boxes[0].astype(int)
@@ -103,11 +129,40 @@ def cpu_baseline(frames_np, threads, cfg):
             if x1 > x0 and y1 > y0:
                 face = orc.resize_linear_u8(fr, y0, y1, x0, x1)     # cv2.resize stand-in (no OpenCV here)
                 ref.embed(face)
+
+    # (i) reference-faithful: one frame at a time, torch's intra-op threads = all cores
+    ref = TorchRef(*sds, threads=threads, min_face_size=cfg["min_face"])
+    t0 = time.time()
+    done = 0
+    while time.time() - t0 < budget:
+        one_frame(ref, frames_np[done % len(frames_np)])
         done += 1
     dt = time.time() - t0
-    return {"value": round(done / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+    # (ii) batched over the cores: `threads` workers, each a single-threaded pipeline over its own frames (torch releases the GIL)
+    import concurrent.futures as cf
+    torch.set_num_threads(1)
+    shared = TorchRef(*sds, threads=1, min_face_size=cfg["min_face"])      # inference only: safe to share between the workers
+    stop = time.time() + budget
+    counts = [0] * threads
+
+    def work(j):
+        k = 0
+        while time.time() < stop:
+            one_frame(shared, frames_np[(j + k * threads) % len(frames_np)])
+            k += 1
+        counts[j] = k
+
+    t1 = time.time()
+    with cf.ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    dt2 = time.time() - t1
+    torch.set_num_threads(threads)
+    return {"value": round(done / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port", "cpu": cpu_model_string(),
+            "batched": {"value": round(sum(counts) / dt2, 3), "unit": "frames/s",
+                        "how": f"{threads} single-threaded frame pipelines side by side, {sum(counts)} frames in {dt2:.1f} s"},
             "sample": f"{done} frames of the same synthetic {H}p clip in {dt:.1f} s, torch-CPU fp32 restatement of the "
-                      f"reference path (oracle/torch_ref.py), one frame at a time like server/model.py:42-59"}
+                      f"reference path (oracle/torch_ref.py), one frame at a time like server/model.py:42-59, "
+                      f"torch.set_num_threads({threads}) = every core this process may use"}
 
 
 def parse_args(argv=None):
@@ -129,9 +184,12 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo to rehearse N>1 on one GPU")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="batches in flight per GPU: each gets its own context, HIP stream and host thread; 1 = strictly sequential")
-    ap.add_argument("--embed-group", type=int, default=1,
-                    help="steps whose faces each worker embeds in ONE InceptionResnetV1 call (trl_detect_crop per step, then one "
-                         "trl_facenet_embed_masked): same bits, the embedder's ~100 small launches amortise over more faces")
+    ap.add_argument("--embed-group", type=int, default=3,
+                    help="consecutive steps whose crops the decoupled embedder embeds in ONE InceptionResnetV1 call (trl_detect_crop per "
+                         "step into a ring, then one trl_facenet_embed_masked): same bits, ~100 small launches amortised over G x 256 faces")
+    ap.add_argument("--driver", default="single", choices=["threads", "single"],
+                    help="how the batches in flight are driven: one host thread per context (blocking trl_detect_embed calls, GIL "
+                         "released) or ONE host thread over all contexts (trl_detect_embed_begin / _end)")
     ap.add_argument("--master-port", type=int, default=None)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the per-step collective even with ONE rank: exercises the RCCL branch "
@@ -215,6 +273,7 @@ def main():
     streams = [torch.cuda.Stream(dev) for _ in range(F)]
     eng = engs[0]
     drift_eng = Engine(blob, device=local) if F > 1 else eng      # the main thread's context (drift kernels)
+    embed_eng = Engine(blob, **ekw) if (args.embed_group > 1 and args.driver == "single") else None   # the decoupled embedder's context
     sharded = args.mode == "sharded"
     frame_count = n * (world if sharded else 1) * 4    # 30 fps clip sampled every 4th frame (model.py:40)
 
@@ -275,13 +334,32 @@ def main():
                 del p["faces"]
                 yield p, tm
 
-        if F == 1:
+        if F == 1 and args.driver == "threads":
             for g0 in range(0, k, G):
                 for out, tm in group(eng, 0, list(range(g0, min(k, g0 + G)))):
                     d = finish(out)
                     for key in acc:
                         acc[key] += tm[key]
                     last = (out, d)
+            return last, acc
+        if args.driver == "single":
+            # ONE host thread over all contexts (pipeline.detect_embed_overlapped): step i is queued on context i % F
+            # (trl_detect_embed_begin returns without synchronising) and finished right before that context is needed again; with
+            # G > 1 the cascades write their crops into a ring and ONE embedder context embeds every G consecutive steps' faces in
+            # one call on its own stream (bit-identical results, the embedder's ~100 launches amortise over G x 256 faces).
+            from truely_amd.pipeline import detect_embed_overlapped
+
+            def on_detect(i, j):
+                tm = engs[j].timings()
+                for key in acc:
+                    acc[key] += tm[key]
+
+            def on_result(i, out):
+                nonlocal last
+                last = (out, finish(out))
+
+            detect_embed_overlapped(engs, lambda i, j: batch_input(j, i + F < k), on_result=on_result, streams=streams,
+                                    embed_group=G, embed_engine=embed_eng, n_batches=k, on_detect=on_detect)
             return last, acc
         qs = [queue.Queue() for _ in range(F)]
 
@@ -368,9 +446,10 @@ def main():
                        "frames_per_gpu": n, "height": H, "width": W, "weights": "seeded synthetic (no checkpoints offline)",
                        "prelu_slopes": args.prelu, "min_face_size": cfg["min_face"], "pyramid_levels": eng.levels(H, W),
                        "valid_faces": int(out["valid"].sum().item()), "score": d["score"], "scores": scores,
+                       "candidates_per_step": dict(zip(("rnet", "onet"), eng.stage_totals())),
                        "emb_crc32": zlib.crc32(emb_all.tobytes()), "mode": args.mode, "ingest": args.ingest,
                        "pnet_path": "fused" if eng.cfg.pnet_mode == 0 else "generic layers",
-                       "parallelism": par, "backend": args.backend if use_dist else None, "batches_in_flight": F,
+                       "parallelism": par, "backend": args.backend if use_dist else None, "batches_in_flight": F, "driver": args.driver,
                        "embed_group": max(1, args.embed_group)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -381,7 +460,7 @@ def main():
                          "pyramid_ms_per_step": round(pyr_ms / args.steps, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, len(os.sched_getaffinity(0)))
+            threads = host_cores()
             res["cpu_baseline"] = cpu_baseline(frames_np, threads, cfg)
         else:
             res["cpu_baseline"] = None

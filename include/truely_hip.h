@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 4
+#define TRL_ABI_VERSION 5
 
 typedef enum {
     TRL_OK = 0,
@@ -117,6 +117,18 @@ int  trl_detect_crop(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
                      float* d_box, float* d_prob, int32_t* d_rect, uint8_t* d_valid, float* d_faces, void* stream);
 int  trl_facenet_embed_masked(trl_ctx* ctx, const float* d_faces, const uint8_t* d_valid, int n, int h, int w, float* d_emb, void* stream);
 
+/* The same two calls split into "queue" and "finish", so ONE host thread can keep several contexts (one per batch in flight, or
+ * one per GPU) busy without a thread per context: *_begin validates, queues every kernel of the call on `stream` and returns
+ * without synchronising; trl_detect_embed_end is the call's one host synchronisation, checks the candidate capacities and -- rarely,
+ * when an optimistic R-/O-Net batch capacity was too small -- re-runs the call before returning.  Outputs are valid after _end.  A
+ * context holds at most one call in flight (TRL_ERR_STATE otherwise); the buffers must stay alive until _end returns.
+ * server/model.py:42-59 is strictly one frame at a time; this is the batched, overlapped form of the same two library calls. */
+int  trl_detect_embed_begin(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
+                            float* d_box, float* d_prob, int32_t* d_rect, uint8_t* d_valid, float* d_emb, void* stream);
+int  trl_detect_crop_begin(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
+                           float* d_box, float* d_prob, int32_t* d_rect, uint8_t* d_valid, float* d_faces, void* stream);
+int  trl_detect_embed_end(trl_ctx* ctx);
+
 /* server/model.py:60-66,70,75,86-95: cosine similarity against the last embedded frame, the
  * run-length counter, and the 0..100 score.  n = number of sampled frames (in time order),
  * frame_count = frames decoded, fps as int(cap.get(CAP_PROP_FPS)) (model.py:28).
@@ -173,6 +185,8 @@ int  trl_debug_crop_aligned(trl_ctx* ctx, const uint8_t* d_frames, int n, int H,
  * out[0] = PNet kernel (fused: the one persistent launch; generic: sum over levels),
  * out[1] = whole call, out[2] = number of PNet launches timed, out[3] = pyramid kernel. */
 int  trl_debug_timings(trl_ctx* ctx, float* out4);
+/* R-Net / O-Net candidate totals of the last call over the whole batch: h_out2[0] = boxes that entered stage 2, [1] = stage 3 */
+int  trl_debug_stage_totals(trl_ctx* ctx, int32_t* h_out2);
 /* execution span (first workgroup start -> last workgroup end, device wall clock) of the last fused PNet launch, in ms:
  * the kernel's duration as rocprofv3 reports it, free of stream-queueing time when several contexts share the GPU */
 int  trl_debug_pnet_kernel_ms(trl_ctx* ctx, float* ms);

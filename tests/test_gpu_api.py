@@ -421,3 +421,83 @@ def test_grouped_embedding_is_bit_identical(engine, blob):
     b = analyze_video(fr, fps=30, engines=[engine, Engine(blob)], batch=4, embed_group=2)
     assert a["score"] == b["score"] and torch.equal(a["emb"], b["emb"]) and torch.equal(a["sims"], b["sims"])
     assert not ref["valid"][5] and (ref["emb"][5] == 0).all()
+
+
+@pytest.mark.parametrize("F,G", [(1, 1), (2, 1), (1, 3), (2, 3), (3, 2), (2, 4)])
+def test_overlapped_pipeline_is_bit_identical(engine, blob, F, G):
+    """pipeline.detect_embed_overlapped (what bench.py and analyze_video(engines=...) run): ONE host thread, F contexts driven through
+    trl_detect_embed_begin / _end, and -- for G > 1 -- the decoupled embedder that embeds every G consecutive batches' crops from
+    the ring in one call.  Batch order, the ring's wrap-around, a short last batch and faceless frames included: the bits are
+    those of a plain per-batch trl_detect_embed."""
+    from truely_amd.engine import Engine
+    from truely_amd.pipeline import detect_embed_overlapped
+    fr = truely_amd.synthetic.synthetic_frames(46, 180, 320, seed=61)
+    fr[7] = 127
+    fr[40:44] = 0                                               # a whole faceless batch
+    batches = [fr[i:i + 4] for i in range(0, 46, 4)]            # 12 batches, the last one short (2 frames)
+    ref = [engine.detect_embed(b) for b in batches]
+    engs = [Engine(blob) for _ in range(F)]
+    order = []
+    outs = detect_embed_overlapped(engs, batches, on_result=lambda i, o: order.append(i), embed_group=G)
+    assert order == list(range(len(batches)))
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        assert "faces" not in o
+        for k in ("box", "prob", "rect", "valid", "emb"):
+            assert torch.equal(o[k], r[k]), (i, k)
+    assert sum(int(r["valid"].sum()) for r in ref) >= 8
+
+
+def test_begin_end_contract(engine):
+    """trl_detect_embed_begin / _end: one call in flight per context, _end without _begin is an error, and a failed _begin leaves
+    the context usable."""
+    from truely_amd._lib import TrlError
+    fr = truely_amd.synthetic.synthetic_frames(3, 180, 320, seed=3)
+    ref = engine.detect_embed(fr)
+    from truely_amd import _lib
+    with pytest.raises(TrlError):
+        _lib.check(engine.lib.trl_detect_embed_end(engine._h))  # nothing in flight
+    engine.detect_embed_begin(fr)
+    with pytest.raises(TrlError):
+        engine.detect_embed_begin(fr)                            # second call on a busy context
+    out = engine.detect_embed_end()
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        assert torch.equal(out[k], ref[k]), k
+    out2 = engine.detect_embed(fr)                               # the blocking call still works afterwards
+    assert torch.equal(out2["emb"], ref["emb"])
+
+
+def test_large_embedder_batches_cross_kernel_families(engine, oracle):
+    """ONE embedder call over more than 335 faces at 80x80 pushes block35's GEMMs past M = 16384 rows: the small-map family
+    (fn_conv, 16x16x4 MFMA, grouped launches) hands over to the generic conv_tap kernels (32x32x2 MFMA).  bench.py's grouped
+    embedder (768 faces per call) runs exactly that.  The embeddings must be the bits of 256-face calls and of the oracle --
+    and again with the small-map family switched off altogether (TRL_NO_FNCONV=1, a fresh process: the switch is read once)."""
+    import subprocess
+    import sys
+    fr = truely_amd.synthetic.synthetic_frames(8, 360, 640, seed=11)
+    c = engine.detect_crop(fr)
+    v = c["valid"].bool()
+    assert int(v.sum()) >= 2
+    base = c["faces"][v]
+    rng = torch.Generator(device="cpu").manual_seed(5)
+    reps = (400 + base.shape[0] - 1) // base.shape[0]
+    faces = base.repeat(reps, 1, 1, 1)[:400].clone()
+    faces += (torch.rand(faces.shape, generator=rng) * (1 / 255.0)).to(faces.device)      # 400 different crops
+    valid = torch.ones(400, dtype=torch.uint8)
+    valid[[3, 77, 399]] = 0
+    big = engine.embed_faces(faces, valid)
+    small = torch.cat([engine.embed_faces(faces[i:i + 200], valid[i:i + 200]) for i in (0, 200)])
+    assert torch.equal(big, small)
+    assert (big[[3, 77, 399]] == 0).all()
+    idx = [0, 1, 199, 200, 336, 398]
+    ref = oracle.facenet(faces[idx].cpu().numpy())
+    assert np.array_equal(big[idx].cpu().numpy(), ref)
+    np.save("/tmp/_trl_faces400.npy", faces.cpu().numpy())
+    np.save("/tmp/_trl_emb400.npy", big.cpu().numpy())
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import truely_amd; from truely_amd.engine import Engine; "
+            "e = Engine(truely_amd.weights.synthetic_blob(0)); f = torch.from_numpy(np.load('/tmp/_trl_faces400.npy')); "
+            "v = torch.ones(400, dtype=torch.uint8); v[[3, 77, 399]] = 0; "
+            "g = e.embed_faces(f, v).cpu().numpy(); assert np.array_equal(g, np.load('/tmp/_trl_emb400.npy')); print('same')"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, TRL_NO_FNCONV="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]

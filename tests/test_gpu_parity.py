@@ -261,30 +261,71 @@ def test_random_shapes_match_oracle(engine, oracle):
             raise AssertionError(f"case {t}: {n} x {H}x{W}: {e}") from e
 
 
-@pytest.mark.parametrize("variant", ["slopes_above_one", "negative_slopes"])
+def _slope_variant_blob(variant):
+    from truely_amd import weights
+    sds = [dict(sd) for sd in weights.synthetic_state_dicts(0)]
+    if variant == "generalise_prelu":                           # what bench.py --prelu general runs
+        weights.generalise_prelu(sds)
+        return weights.pack_state_dicts(*sds)
+    for net, keys in ((sds[0], ("prelu1.weight", "prelu2.weight", "prelu3.weight")), (sds[1], ("prelu1.weight",)),
+                      (sds[2], ("prelu1.weight",))):          # PNet (fused kernel) and the R-/O-Net front kernels
+        for key in keys:
+            w = np.array(net[key], np.float32, copy=True)
+            if variant == "slopes_above_one":                   # k_pnet_fused<false, false>, front MODE 1
+                w[::2] = 1.25
+            elif variant == "negative_slopes":                  # all <= 1, some negative: k_pnet_fused<true, true>, front MODE 0
+                w[1::3] = -0.2
+            elif variant == "mixed_signs":                      # every class in one layer: k_pnet_fused<false, true>, front MODE 0
+                w[0::4] = 1.5; w[1::4] = -0.35; w[2::4] = 0.0; w[3::4] = 1.0
+            elif variant == "negative_deep_only":               # conv1 slopes stay in [0, 1]: k_pnet_fused<true, false> with negative conv2/3 slopes
+                if key != "prelu1.weight":
+                    w[::2] = -0.15
+            net[key] = w
+    return weights.pack_state_dicts(*sds)
+
+
+@pytest.mark.parametrize("variant", ["slopes_above_one", "negative_slopes", "mixed_signs", "negative_deep_only", "generalise_prelu"])
 def test_cascade_fused_pnet_prelu_variants(variant):
-    """PReLU slopes outside [0, 1] take the generic kernel instantiation; a negative conv1 slope also forbids
-    the pool-before-PReLU shortcut.  Same bit-exact bar."""
+    """A trained checkpoint's PReLU slopes are unconstrained (server/model.py:18 loads them).  Every slope class takes the same
+    pool-before-PReLU kernels: slopes above 1 select min(v, s v) through med3, a negative conv1 slope pools the window's min next
+    to its max (max_i prelu(v_i) = max(m, s n)).  Same bit-exact bar as the seeded slopes: the whole cascade record, the fused
+    kernel's own probability / regression maps (thr0 = 0), and the front kernels on chosen boxes."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle.oracle import Oracle
     from truely_amd.engine import Engine
-    from truely_amd import weights
-    sds = [dict(sd) for sd in weights.synthetic_state_dicts(0)]
-    for net, keys in ((sds[0], ("prelu1.weight", "prelu2.weight", "prelu3.weight")), (sds[1], ("prelu1.weight",)),
-                      (sds[2], ("prelu1.weight",))):          # PNet (fused kernel) and the R-/O-Net front kernels
-        for key in keys:
-            w = np.array(net[key], np.float32, copy=True)
-            if variant == "slopes_above_one":
-                w[::2] = 1.25
-            else:
-                w[1::3] = -0.2
-            net[key] = w
-    blob = weights.pack_state_dicts(*sds)
+    blob = _slope_variant_blob(variant)
     eng, orc = Engine(blob), Oracle(blob)
     _check_cascade(eng, orc, frames_small(4, 180, 320))
     _check_cascade(eng, orc, truely_amd.synthetic.synthetic_frames(2, 97, 131, seed=21))
+    # the fused kernel's own maps, interior and edge tiles, sub-threshold cells included
+    eng0 = Engine(blob, thresholds=(0.0, 0.7, 0.7), cap_level=3072, cap_frame=3072)
+    H, W = 97, 131
+    fr = truely_amd.synthetic.synthetic_frames(1, H, W, seed=23)
+    eng0.poison_workspaces(0xFF)
+    eng0.mtcnn_detect(fr)
+    for l, (sc, h, w) in enumerate(orc.scales(H, W)):
+        p_ref, r_ref = orc.pnet_level(orc.area_resample_norm(fr[0], 0, H, 0, W, h, w))
+        rows = eng0.level_cands(0, l)
+        assert len(rows) == p_ref.size
+        assert np.array_equal(rows["score"], p_ref.reshape(-1)), f"level {l}: prob map"
+        assert np.array_equal(rows["reg"], r_ref.reshape(-1, 4)), f"level {l}: reg map"
+    # the front kernels (crop + conv1 + pool + PReLU) on boxes of every crop path
+    fr1 = truely_amd.synthetic.synthetic_frames(1, 211, 333, seed=11)[0]
+    boxes = np.array([[10, 10, 40, 42], [50.3, 40.2, 150.8, 140.7], [0.4, 0.6, 332.9, 210.9], [-30.5, -20.5, 80.5, 90.5],
+                      [200, 100, 206, 107], [120, 60, 330, 209]], np.float32)
+    tb = np.trunc(boxes).astype(np.int32)
+    x, y = np.maximum(tb[:, 0], 1), np.maximum(tb[:, 1], 1)
+    ex, ey = np.minimum(tb[:, 2], 333), np.minimum(tb[:, 3], 211)
+    for net in (24, 48):
+        crops = np.stack([orc.area_resample_norm(fr1, y[k] - 1, ey[k], x[k] - 1, ex[k], net, net) for k in range(len(boxes))])
+        out = eng.front_net(fr1, boxes, net).cpu().numpy()
+        ref = orc.rnet(crops) if net == 24 else orc.onet(crops)
+        assert np.array_equal(out[:, 2:6], ref[1]), f"net {net}: regression"
+        assert np.array_equal(_softmax_p1(orc, out[:, :2]), ref[0]), f"net {net}: probability"
+        if net == 48:
+            assert np.array_equal(out[:, 6:16], ref[2])
 
 
 def test_cascade_fused_pnet_720p(engine, oracle):

@@ -1,0 +1,64 @@
+"""Per-kernel register / LDS / scratch use of libtruely_hip.so, read from the code object's metadata notes.
+
+    python tools/kernel_resources.py [filter]      # exits 1 if any kernel uses scratch (spills)
+
+hipcc embeds one gfx950 code object per translation unit in the .so's .hip_fatbin section (clang offload bundles); their
+AMDGPU metadata notes are printed with llvm-readelf.  Every hand-written kernel is expected to have
+private_segment_fixed_size == 0."""
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "truely-real-time-ai-generated-video-detection-framework-for-social-platforms_amd", "libtruely_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def code_objects(lib=LIB):
+    """The gfx950 code objects of the library (one per translation unit): the .hip_fatbin section is a run of uncompressed
+    clang offload bundles -- magic, entry count, then (offset, size, triple) records."""
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib, os.path.join(td, "ignored.so")])
+        d = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    pos = d.find(magic)
+    while pos >= 0:
+        (n,) = struct.unpack_from("<Q", d, pos + 24)
+        q = pos + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", d, q)
+            triple = d[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if "gfx950" in triple and size:
+                yield d[pos + off:pos + off + size]
+        pos = d.find(magic, pos + 1)
+
+
+def kernels(lib=LIB):
+    out = []
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co); f.flush()
+            txt = subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", f.name], text=True)
+        for blk in txt.split("- .agpr_count:")[1:]:
+            g = lambda k: re.search(rf"\.{k}:\s+(\S+)", blk)
+            out.append(dict(name=g("name").group(1), vgpr=int(g("vgpr_count").group(1)), agpr=int(blk.split()[0]),
+                            sgpr=int(g("sgpr_count").group(1)), lds=int(g("group_segment_fixed_size").group(1)),
+                            scratch=int(g("private_segment_fixed_size").group(1))))
+    return out
+
+
+if __name__ == "__main__":
+    flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    bad = 0
+    for k in sorted(kernels(), key=lambda k: k["name"]):
+        dem = subprocess.run(["c++filt", k["name"]], capture_output=True, text=True).stdout.strip()
+        if flt and flt not in dem:
+            continue
+        print(f"{dem[:110]:110s} vgpr {k['vgpr']:3d} agpr {k['agpr']:3d} sgpr {k['sgpr']:3d} lds {k['lds']:6d} scratch {k['scratch']}")
+        bad += k["scratch"] > 0
+    sys.exit(1 if bad else 0)

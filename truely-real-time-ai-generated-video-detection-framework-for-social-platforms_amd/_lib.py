@@ -37,6 +37,9 @@ _SIGNATURES = {
     "trl_facenet_embed": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "trl_detect_embed": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "trl_detect_crop": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "trl_detect_embed_begin": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "trl_detect_crop_begin": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "trl_detect_embed_end": (C.c_int, [_vp]),
     "trl_facenet_embed_masked": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "trl_drift_score": (C.c_int, [_vp, _vp, _vp, _i, C.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "trl_ingest_nv12": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
@@ -53,6 +56,7 @@ _SIGNATURES = {
     "trl_debug_crop_resize": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "trl_debug_crop_aligned": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "trl_debug_timings": (C.c_int, [_vp, C.POINTER(_f)]),
+    "trl_debug_stage_totals": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "trl_debug_pnet_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
 }
 EXPORTS = tuple(_SIGNATURES)
@@ -76,7 +80,7 @@ def load(path: str | None = None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.trl_abi_version() != 4:
+    if lib.trl_abi_version() != 5:
         raise ImportError("libtruely_hip ABI mismatch")
     _lib = lib
     return lib

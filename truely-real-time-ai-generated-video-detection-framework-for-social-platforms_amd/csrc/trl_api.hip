@@ -370,44 +370,86 @@ int trl_facenet_embed(trl_ctx* c, const float* d_faces, int n, int h, int w, flo
 
 // model.py:47-58 (detect, largest box, crop + resize) and optionally :59 (embed).  d_faces_out != null: the crops are written there
 // (caller-owned [n][S][S][3] f32) and the embedder is NOT run (trl_detect_crop); else they live in scratch and are embedded.
-static int detect_embed_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
-                             uint8_t* d_valid, float* d_emb, float* d_faces_out, void* stream) {
+// Split in two so a host thread can keep several contexts busy: detect_embed_enqueue() queues ONE attempt of the call on the
+// stream and returns; detect_embed_wait() is the call's one host synchronisation, the capacity check and -- rarely -- the re-run.
+static int detect_embed_enqueue(trl_ctx* c) {
+    const trl_ctx::Pending& q = c->pend;
+    hipStream_t s = (hipStream_t)q.stream;
+    const int n = q.n, H = q.H, W = q.W;
+    const int S = c->cfg.embed_mode == 0 ? 80 : 160;
+    TRL_HIP(hipEventRecord(c->ev_call0, s));
+    TRL_CHECK(trl_cascade_detect(c, q.frames, n, H, W, s));
+    float* pts0 = nullptr;
+    if (c->cfg.embed_mode == 3) {                // the largest face's landmarks steer the aligned crop
+        pts0 = (float*)c->arena.alloc((size_t)n * 40);
+        if (!pts0) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
+    }
+    TRL_CHECK(trl_cascade_finish(c, q.frames, n, H, W, nullptr, nullptr, nullptr, nullptr, q.box, q.prob, q.rect, q.valid, pts0, s));
+    float* faces = q.faces_out;
+    if (!faces) {
+        c->scratch.reset();                      // stream order: the cascade's kernels are done with it before these run
+        faces = (float*)c->scratch.alloc((size_t)n * S * S * 3 * 4);
+        if (!faces) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
+    }
+    if (c->cfg.embed_mode == 0) TRL_CHECK(trl_launch_crop_resize80(q.frames, n, H, W, q.rect, q.valid, faces, s));
+    else if (c->cfg.embed_mode == 3) TRL_CHECK(trl_launch_crop_aligned(q.frames, n, H, W, pts0, q.valid, S, true, faces, s));
+    else TRL_CHECK(trl_launch_crop_area_std(q.frames, n, H, W, q.rect, q.valid, S, c->cfg.embed_mode == 2, faces, s));
+    if (!q.faces_out) TRL_CHECK(trl_run_facenet(c, faces, n, S, S, q.valid, q.emb, s));
+    TRL_HIP(hipEventRecord(c->ev_call1, s));
+    return TRL_OK;
+}
+
+static int detect_embed_begin(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
+                              uint8_t* d_valid, float* d_emb, float* d_faces_out, void* stream) {
     TRL_CHECK(check_call(c, d_frames, n, H, W));
+    if (c->pend.active) { trl_set_error("the context already has a call in flight: trl_detect_embed_end() first"); return TRL_ERR_STATE; }
     if (!d_box || !d_prob || !d_rect || !d_valid || (!d_emb && !d_faces_out)) { trl_set_error("null output"); return TRL_ERR_INVALID; }
-    hipStream_t s = (hipStream_t)stream;
     TRL_HIP(hipSetDevice(c->cfg.device));
     const int S = c->cfg.embed_mode == 0 ? 80 : 160;
     c->scratch_after_cascade = d_faces_out ? 0 : (size_t)n * ((size_t)S * S * 110 + 400000) * 4 + (8u << 20);
-    for (int attempt = 0;; attempt++) {
-        TRL_HIP(hipEventRecord(c->ev_call0, s));
-        TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
-        float* pts0 = nullptr;
-        if (c->cfg.embed_mode == 3) {                // the largest face's landmarks steer the aligned crop
-            pts0 = (float*)c->arena.alloc((size_t)n * 40);
-            if (!pts0) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
-        }
-        TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, nullptr, nullptr, nullptr, nullptr, d_box, d_prob, d_rect, d_valid, pts0, s));
-        float* faces = d_faces_out;
-        if (!faces) {
-            c->scratch.reset();                      // stream order: the cascade's kernels are done with it before these run
-            faces = (float*)c->scratch.alloc((size_t)n * S * S * 3 * 4);
-            if (!faces) { trl_set_error("arena exhausted"); return TRL_ERR_STATE; }
-        }
-        if (c->cfg.embed_mode == 0) TRL_CHECK(trl_launch_crop_resize80(d_frames, n, H, W, d_rect, d_valid, faces, s));
-        else if (c->cfg.embed_mode == 3) TRL_CHECK(trl_launch_crop_aligned(d_frames, n, H, W, pts0, d_valid, S, true, faces, s));
-        else TRL_CHECK(trl_launch_crop_area_std(d_frames, n, H, W, d_rect, d_valid, S, c->cfg.embed_mode == 2, faces, s));
-        if (!d_faces_out) TRL_CHECK(trl_run_facenet(c, faces, n, S, S, d_valid, d_emb, s));
-        TRL_HIP(hipEventRecord(c->ev_call1, s));
-        TRL_HIP(hipStreamSynchronize(s));             // the call's one host synchronisation
-        int retry = 0;
-        TRL_CHECK(trl_cascade_check(c, n, &retry));
-        c->last_attempts = attempt + 1;
-        if (!retry) break;                            // (a retry re-runs the call with larger R-/O-Net batch capacities)
-        if (attempt >= 3) { trl_set_error("candidate batch capacity did not converge"); return TRL_ERR_STATE; }
-    }
-    collect_timings(c);
-    return TRL_OK;
+    c->pend = trl_ctx::Pending{true, 0, d_frames, n, H, W, d_box, d_prob, d_rect, d_valid, d_emb, d_faces_out, stream};
+    const int st = detect_embed_enqueue(c);
+    if (st != TRL_OK) c->pend.active = false;
+    return st;
 }
+
+static int detect_embed_wait(trl_ctx* c) {
+    if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
+    if (!c->pend.active) { trl_set_error("no call in flight on this context"); return TRL_ERR_STATE; }
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = (hipStream_t)c->pend.stream;
+    int st = TRL_OK;
+    for (;;) {
+        if ((st = (hipStreamSynchronize(s) == hipSuccess ? TRL_OK : TRL_ERR_HIP)) != TRL_OK) { trl_set_error("hipStreamSynchronize: %s", hipGetErrorString(hipGetLastError())); break; }
+        int retry = 0;
+        if ((st = trl_cascade_check(c, c->pend.n, &retry)) != TRL_OK) break;
+        c->last_attempts = ++c->pend.attempt;
+        if (!retry) break;                            // (a retry re-runs the call with larger R-/O-Net batch capacities)
+        if (c->pend.attempt >= 4) { trl_set_error("candidate batch capacity did not converge"); st = TRL_ERR_STATE; break; }
+        if ((st = detect_embed_enqueue(c)) != TRL_OK) break;
+    }
+    c->pend.active = false;
+    if (st == TRL_OK) collect_timings(c);
+    return st;
+}
+
+static int detect_embed_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
+                             uint8_t* d_valid, float* d_emb, float* d_faces_out, void* stream) {
+    TRL_CHECK(detect_embed_begin(c, d_frames, n, H, W, d_box, d_prob, d_rect, d_valid, d_emb, d_faces_out, stream));
+    return detect_embed_wait(c);
+}
+
+int trl_detect_embed_begin(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
+                           uint8_t* d_valid, float* d_emb, void* stream) {
+    if (!d_emb) { trl_set_error("null output"); return TRL_ERR_INVALID; }
+    return detect_embed_begin(c, d_frames, n, H, W, d_box, d_prob, d_rect, d_valid, d_emb, nullptr, stream);
+}
+int trl_detect_crop_begin(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
+                          uint8_t* d_valid, float* d_faces, void* stream) {
+    if (!d_faces) { trl_set_error("null output"); return TRL_ERR_INVALID; }
+    return detect_embed_begin(c, d_frames, n, H, W, d_box, d_prob, d_rect, d_valid, nullptr, d_faces, stream);
+}
+int trl_detect_embed_end(trl_ctx* c) { return detect_embed_wait(c); }
 
 int trl_detect_embed(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_box, float* d_prob, int32_t* d_rect,
                      uint8_t* d_valid, float* d_emb, void* stream) {
@@ -615,6 +657,13 @@ int trl_debug_batch_capacity(trl_ctx* c, float t2_per_frame, float t3_per_frame,
     if (t2_per_frame > 0.f) c->t2_per_frame = t2_per_frame;
     if (t3_per_frame > 0.f) c->t3_per_frame = t3_per_frame;
     if (last_attempts) *last_attempts = c->last_attempts;
+    return TRL_OK;
+}
+
+// R-Net / O-Net candidate totals of the last call (what the front kernels and the tails processed)
+int trl_debug_stage_totals(trl_ctx* c, int32_t* h_out2) {
+    if (!c || !h_out2) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
+    h_out2[0] = c->h_pinned[4 + 4]; h_out2[1] = c->h_pinned[4 + 5];
     return TRL_OK;
 }
 

@@ -97,6 +97,35 @@ __device__ __forceinline__ float vmax3_nc(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ float vmin_nc(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin3_nc(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmed3_nc(float a, float b, float c) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// PReLU for ANY slope in two VALU instructions.  prelu(v) = v > 0 ? v : s v is max(v, s v) for s <= 1 (negative slopes
+// included: then s v >= 0 >= v for v <= 0 and s v < 0 < v for v > 0) and min(v, s v) for s > 1; med3(v, s v, c) with the
+// per-channel constant c = +inf / -inf selects between the two.  Exact: the result is one of the two operands, the same
+// product the reference expression rounds (only the sign of a zero result can differ, which no later step observes).
+__device__ __forceinline__ float trl_prelu_sel(float slope) { return slope > 1.f ? -__builtin_inff() : __builtin_inff(); }
+__device__ __forceinline__ float trl_prelu_med3(float v, float slope, float sel) { return vmed3_nc(v, slope * v, sel); }
+// max over a pool window of prelu(v_i), from the window's max m and min n only (PReLU after the pool, any slope sign):
+//   s >= 0: prelu is monotone, the max is prelu(m);
+//   s <  0: prelu(v) = max(v, s v), so max_i prelu(v_i) = max(max_i v_i, max_i s v_i) = max(m, s n)  (s n is the exact product
+//           of the element that attains the min: float multiplication by a constant is monotone).
+// Both are med3(m, s x, sel) with x = (s < 0 ? n : m).
+__device__ __forceinline__ float trl_prelu_pooled(float m, float n, float slope, float sel) {
+    return vmed3_nc(m, slope * (slope < 0.f ? n : m), sel);
+}
 __device__ __forceinline__ int trl_live_rows(const ConvArgs& a) {   // rows of the GEMM that exist (uniform: scalar loads)
     if (!a.m_dev) return a.M;
     int t = *a.m_dev - a.m_base;

@@ -48,7 +48,7 @@ struct trl_ctx {
     int pnet_ev_used = 0;
     float last_ms[4] = {0, 0, 0, 0};
     int pnet_mono1 = 0;              // conv1 PReLU slopes all >= 0
-    int pnet_unit = 0;               // every PNet PReLU slope in [0, 1]
+    int pnet_unit = 0;               // no PNet PReLU slope above 1 (negative ones allowed): prelu(v) == max(v, s v)
     int32_t* pnet_cursor = nullptr;           // device: 8 per-XCD tile cursors of the fused PNet launch
     unsigned long long* pnet_clk = nullptr;   // device: first-start / last-end wall clock of the fused PNet launch
     float pnet_kernel_ms = 0.f;      // its span in ms (collect_timings)
@@ -60,6 +60,13 @@ struct trl_ctx {
     int last_attempts = 0;           // attempts the last call took (test hook)
     size_t scratch_after_cascade = 0;   // scratch bytes the rest of the call needs (crops + FaceNet): sized with the cascade's
     int rnet_front_mode = -1, onet_front_mode = -1;   // conv1 PReLU slope class (trl_front.hip), -1 = not yet classified
+    // the call queued by trl_detect_embed_begin / trl_detect_crop_begin and not yet finished by trl_detect_embed_end
+    struct Pending {
+        bool active = false; int attempt = 0;
+        const uint8_t* frames = nullptr; int n = 0, H = 0, W = 0;
+        float* box = nullptr; float* prob = nullptr; int32_t* rect = nullptr; uint8_t* valid = nullptr; float* emb = nullptr;
+        float* faces_out = nullptr; void* stream = nullptr;
+    } pend;
     uint32_t* pyr_tab = nullptr;     // pyramid bin-edge tables for the last (H, W)
     int pyr_tab_H = 0, pyr_tab_W = 0;
 };

@@ -72,15 +72,19 @@ __device__ __forceinline__ float fn_finish(const ConvArgs& a, const FnCol& c, fl
 }
 
 // ---- single chain: the four waves tile BM x BN as WM x WN ----------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+// DBG (both kernels): the diagnostic instantiation honours g.dbg (per-wave cycle stamps) and g.skip (timing-only ablations); the
+// production instantiation reads neither.
+template <int BM, int BN, int WM, int WN, bool DBG>
 __global__ __launch_bounds__(256) void fn_conv(FnGroup g) {
+    unsigned long long* const dbgp = DBG ? g.dbg : nullptr;   // compile-time null / 0 in production
+    const int skipm = DBG ? g.skip : 0;
     const int z = blockIdx.z;
     if ((int)blockIdx.x >= g.gx[z] || (int)blockIdx.y >= g.gy[z]) return;
     // one batch of scalar loads for the conv's arguments (indexing the kernarg by a runtime z field by field cost ~15
     // dependent scalar-load round trips, 4k cycles, before the first global load was even issued)
     const ConvArgs a = g.a[z];
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
-    if (g.dbg) st0 = __builtin_readcyclecounter();
+    if (dbgp) st0 = __builtin_readcyclecounter();
     static_assert(WM * WN == 4 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "tile shape");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int LDB = fn_ld(BN);
@@ -136,14 +140,14 @@ __global__ __launch_bounds__(256) void fn_conv(FnGroup g) {
             f32x4m v = {0.f, 0.f, 0.f, 0.f};
             bool ok = ain[i][0];
             if (pad) ok = ok && (unsigned)(iy0v[i] + ky) < (unsigned)a.H && (unsigned)(ix0v[i] + kx) < (unsigned)a.W;
-            if (ok && !(g.skip & 2)) v = *reinterpret_cast<const f32x4m*>(a.x + (aoff[i] + soff));
+            if (ok && !(skipm & 2)) v = *reinterpret_cast<const f32x4m*>(a.x + (aoff[i] + soff));
             ar[st][i] = v;
         }
         const float* wrow = a.w + (size_t)k0 * a.ldw;
 #pragma unroll
         for (int i = 0; i < BPT; i++) {
             f32x4m v = {0.f, 0.f, 0.f, 0.f};
-            if ((BSL % 256 == 0 || tid + 256 * i < BSL) && !(g.skip & 2)) v = *reinterpret_cast<const f32x4m*>(wrow + boff[i]);
+            if ((BSL % 256 == 0 || tid + 256 * i < BSL) && !(skipm & 2)) v = *reinterpret_cast<const f32x4m*>(wrow + boff[i]);
             br[st][i] = v;
         }
         k0 += FBK; c0 += FBK;
@@ -218,13 +222,13 @@ __global__ __launch_bounds__(256) void fn_conv(FnGroup g) {
                 rv[tm][tn][q] = (rp && mr < a.M && n < a.Cout) ? rp[(size_t)mr * a.ldres + n] : 0.f;
             }
     }
-    if (g.dbg) st1 = __builtin_readcyclecounter();
+    if (dbgp) st1 = __builtin_readcyclecounter();
     // chunk c lives in LDS buffer c & 1.  Per chunk: read its operands, drop chunk c+1 into the other buffer (free since the
     // barrier that ended chunk c-1), issue the global loads of chunk c+FDEPTH+... , multiply, ONE barrier.
     stage(std::integral_constant<int, 0>{}, 0);
     if (FDEPTH < nchunks) load(std::integral_constant<int, 0>{});
     __syncthreads();
-    if (g.dbg) st2 = __builtin_readcyclecounter();
+    if (dbgp) st2 = __builtin_readcyclecounter();
     for (int ch = 0; ch < nchunks; ch += FDEPTH) {
         fn_static_for(SEQ, [&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
@@ -234,17 +238,17 @@ __global__ __launch_bounds__(256) void fn_conv(FnGroup g) {
                 fetch(c & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (c + 1 < nchunks) {
-                    if (!(g.skip & 4)) stage(std::integral_constant<int, jn>{}, (c + 1) & 1);
+                    if (!(skipm & 4)) stage(std::integral_constant<int, jn>{}, (c + 1) & 1);
                     if (c + 1 + FDEPTH < nchunks) load(std::integral_constant<int, jn>{});
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(g.skip & 1)) multiply();
+                if (!(skipm & 1)) multiply();
                 __syncthreads();
             }
         });
     }
 
-    if (g.dbg) st3 = __builtin_readcyclecounter();
+    if (dbgp) st3 = __builtin_readcyclecounter();
     float* __restrict__ yp = a.y;
 #pragma unroll
     for (int tn = 0; tn < TN; tn++) {
@@ -258,20 +262,22 @@ __global__ __launch_bounds__(256) void fn_conv(FnGroup g) {
                 if (mr < a.M) yp[(size_t)mr * a.ldy + a.yoff + n + (n >= a.ysplit ? a.yskip : 0)] = fn_finish(a, colc[tn], acc[tm][tn][q], rv[tm][tn][q]);
             }
     }
-    if (g.dbg && lane == 0) {
-        unsigned long long* d = g.dbg + (size_t)(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    if (dbgp && lane == 0) {
+        unsigned long long* d = dbgp + (size_t)(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
         d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = __builtin_readcyclecounter(); d[5] = wall_clock64();
     }
 }
 
 // ---- four chains: wave w owns quarter w of k for the whole BM x BN tile; wave-private staging, no barrier in the K loop --
-template <int BM, int BN>
+template <int BM, int BN, bool DBG>
 __global__ __launch_bounds__(256) void fn_conv_split4(FnGroup g) {
+    unsigned long long* const dbgp = DBG ? g.dbg : nullptr;   // compile-time null / 0 in production
+    const int skipm = DBG ? g.skip : 0;
     const int z = blockIdx.z;
     if ((int)blockIdx.x >= g.gx[z] || (int)blockIdx.y >= g.gy[z]) return;
     const ConvArgs a = g.a[z];                                // one batch of scalar loads (see fn_conv)
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
-    if (g.dbg) st0 = __builtin_readcyclecounter();
+    if (dbgp) st0 = __builtin_readcyclecounter();
     constexpr int TM = BM / 16, TN = BN / 16;
     constexpr int LDB = fn_ld(BN);
     constexpr int APL = BM * (FBK / 4) / 64, BPL = FBK * (BN / 4) / 64;     // float4 slots per lane
@@ -339,12 +345,12 @@ __global__ __launch_bounds__(256) void fn_conv_split4(FnGroup g) {
                 f32x4m v = {0.f, 0.f, 0.f, 0.f};
                 bool ok = true;
                 if (pad) ok = (unsigned)(iy0v[i] + ky) < (unsigned)a.H && (unsigned)(ix0v[i] + kx) < (unsigned)a.W;
-                if (ok && !(g.skip & 2)) v = *reinterpret_cast<const f32x4m*>(a.x + (aoff[i] + soff));
+                if (ok && !(skipm & 2)) v = *reinterpret_cast<const f32x4m*>(a.x + (aoff[i] + soff));
                 ar[st][i] = v;
             }
             const float* wrow = a.w + (size_t)k0 * a.ldw;
 #pragma unroll
-            for (int i = 0; i < BPL; i++) br[st][i] = (g.skip & 2) ? f32x4m{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4m*>(wrow + boff[i]);
+            for (int i = 0; i < BPL; i++) br[st][i] = (skipm & 2) ? f32x4m{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4m*>(wrow + boff[i]);
         }
         k0 += FBK; c0 += FBK;
         if (c0 >= a.Cin) { c0 = 0; if (++kx == a.KW) { kx = 0; ++ky; } }
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(256) void fn_conv_split4(FnGroup g) {
             for (int tn = 0; tn < TN; tn++) bv[s][tn] = Bs[(4 * s + kq) * LDB + tn * 16 + l15];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (g.skip & 1) {      // timing ablation: keep the operand reads alive without the matrix pipe
+        if (skipm & 1) {      // timing ablation: keep the operand reads alive without the matrix pipe
             float t = 0.f;
 #pragma unroll
             for (int s = 0; s < FBK / 4; s++) {
@@ -416,21 +422,21 @@ __global__ __launch_bounds__(256) void fn_conv_split4(FnGroup g) {
         const int n = n0 + tn * 16 + l15;
         rv[blk] = (rp && mr < a.M && n < a.Cout) ? rp[(size_t)mr * a.ldres + n] : 0.f;
     }
-    if (g.dbg) st1 = __builtin_readcyclecounter();
+    if (dbgp) st1 = __builtin_readcyclecounter();
     for (int ch = 0; ch < nchunks; ch += FDEPTH) {
         // wave-private staging: the LDS operations of one wave stay in order, no workgroup barrier needed
         fn_static_for(SEQ, [&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
             if (ch + j < nchunks) {
                 const bool lj = live[j];
-                if (lj && !(g.skip & 4)) stage(J);
-                if (g.dbg && ch + j == 0) { __builtin_amdgcn_s_waitcnt(0); st2 = __builtin_readcyclecounter(); }
+                if (lj && !(skipm & 4)) stage(J);
+                if (dbgp && ch + j == 0) { __builtin_amdgcn_s_waitcnt(0); st2 = __builtin_readcyclecounter(); }
                 if (ch + j + FDEPTH < nchunks) load(J);
                 if (lj) compute();
             }
         });
     }
-    if (g.dbg) st3 = __builtin_readcyclecounter();
+    if (dbgp) st3 = __builtin_readcyclecounter();
     __syncthreads();
     static_assert(SM * sizeof(float) <= 160 * 1024, "LDS per workgroup");
     float* red = sm;                                         // [wave][tm][tn][q][lane]
@@ -453,8 +459,8 @@ __global__ __launch_bounds__(256) void fn_conv_split4(FnGroup g) {
         const float v = (red[e] + red[RED + e]) + (red[2 * RED + e] + red[3 * RED + e]);
         yp[(size_t)mr * a.ldy + a.yoff + n + (n >= a.ysplit ? a.yskip : 0)] = fn_finish(a, cc[tn], v, rv[blk]);
     }
-    if (g.dbg && lane == 0) {
-        unsigned long long* d = g.dbg + (size_t)(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    if (dbgp && lane == 0) {
+        unsigned long long* d = dbgp + (size_t)(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
         d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3; d[4] = __builtin_readcyclecounter(); d[5] = wall_clock64();
     }
 }
@@ -462,20 +468,30 @@ __global__ __launch_bounds__(256) void fn_conv_split4(FnGroup g) {
 struct Tile { int bm, bn; };
 
 template <int BM, int BN, int WM, int WN>
-void launch1(const FnGroup& g, int nz, hipStream_t s) {
+int launch1(const FnGroup& g, int nz, hipStream_t s) {
     int gx = 0, gy = 0;
     for (int z = 0; z < nz; z++) { gx = g.gx[z] > gx ? g.gx[z] : gx; gy = g.gy[z] > gy ? g.gy[z] : gy; }
-    fn_conv<BM, BN, WM, WN><<<dim3(gx, gy, nz), 256, 0, s>>>(g);
+    if (g.dbg || g.skip) fn_conv<BM, BN, WM, WN, true><<<dim3(gx, gy, nz), 256, 0, s>>>(g);
+    else fn_conv<BM, BN, WM, WN, false><<<dim3(gx, gy, nz), 256, 0, s>>>(g);
+    return TRL_OK;
 }
 template <int BM, int BN>
-void launch4(const FnGroup& g, int nz, hipStream_t s) {
+int launch4(const FnGroup& g, int nz, hipStream_t s) {
     int gx = 0, gy = 0;
     for (int z = 0; z < nz; z++) { gx = g.gx[z] > gx ? g.gx[z] : gx; gy = g.gy[z] > gy ? g.gy[z] : gy; }
     constexpr int STG = (BM * LDK + FBK * fn_ld(BN) + 3) & ~3, RED = BM * BN;
     constexpr size_t bytes = sizeof(float) * (size_t)(4 * STG > 4 * RED ? 4 * STG : 4 * RED);
-    static bool attr_set = false;                               // per instantiation
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)fn_conv_split4<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); attr_set = true; }
-    fn_conv_split4<BM, BN><<<dim3(gx, gy, nz), 256, bytes, s>>>(g);
+    // The dynamic-LDS limit is a per-DEVICE function attribute (the 48x64 tile needs 67 KB, over the 64 KB default): set on every
+    // launch -- a process may hold contexts on several devices, and worker threads launch concurrently (a host-side call, no
+    // device work; a process-wide "already set" flag was wrong on both counts).
+    if (g.dbg || g.skip) {
+        TRL_HIP(hipFuncSetAttribute((const void*)fn_conv_split4<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        fn_conv_split4<BM, BN, true><<<dim3(gx, gy, nz), 256, bytes, s>>>(g);
+    } else {
+        TRL_HIP(hipFuncSetAttribute((const void*)fn_conv_split4<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        fn_conv_split4<BM, BN, false><<<dim3(gx, gy, nz), 256, bytes, s>>>(g);
+    }
+    return TRL_OK;
 }
 
 // diagnostic stamps: the k-th launch after trl_debug_fn_arm(k) records per-wave cycle stamps
@@ -556,8 +572,8 @@ int trl_launch_fn_group(const ConvArgs* convs, int nz, hipStream_t s) {
         if (g_dbg_waves > DBG_WAVES) { g.dbg = nullptr; g_dbg_waves = 0; }
         else fprintf(stderr, "[fn stamps] tile %dx%d split4=%d grid %dx%dx%d M=%d N=%d K=%d Cin=%d\n", t.bm, t.bn, (int)sp, gx, gy, nz, convs[0].M, convs[0].Cout, convs[0].K, convs[0].Cin);
     }
-#define FN1(BM, BN, WM, WN) if (t.bm == BM && t.bn == BN) { launch1<BM, BN, WM, WN>(g, nz, s); TRL_LAUNCH_CHECK(); return TRL_OK; }
-#define FN4(BM, BN) if (t.bm == BM && t.bn == BN) { launch4<BM, BN>(g, nz, s); TRL_LAUNCH_CHECK(); return TRL_OK; }
+#define FN1(BM, BN, WM, WN) if (t.bm == BM && t.bn == BN) { TRL_CHECK((launch1<BM, BN, WM, WN>(g, nz, s))); TRL_LAUNCH_CHECK(); return TRL_OK; }
+#define FN4(BM, BN) if (t.bm == BM && t.bn == BN) { TRL_CHECK((launch4<BM, BN>(g, nz, s))); TRL_LAUNCH_CHECK(); return TRL_OK; }
     if (sp) {
         FN4(16, 32) FN4(16, 64) FN4(32, 32) FN4(32, 64) FN4(48, 32) FN4(48, 64)
     } else {

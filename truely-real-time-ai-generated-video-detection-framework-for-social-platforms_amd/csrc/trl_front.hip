@@ -28,11 +28,14 @@ __device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF
     return hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
 }
 
-// MODE: 0 = generic PReLU, applied to every conv1 output before the pool (the reference order);
-//       1 = all slopes >= 0: PReLU is monotone, so it commutes with max and is applied once per POOLED value;
-//       2 = all slopes in [0, 1]: as 1, with prelu(v) == max(v, slope*v) (exact, one VALU op fewer).
+// PReLU is applied once per POOLED value, never to the conv1 map (the reference order is PReLU, then pool; the result is the same
+// bits -- trl_common.h trl_prelu_pooled):
+// MODE: 0 = some slope is negative: the pool keeps the window's min next to its max, max_i prelu(v_i) = med3(m, s (s < 0 ? n : m), +-inf);
+//       1 = all slopes >= 0: PReLU is monotone and commutes with max: med3(m, s m, +-inf) (any slope size);
+//       2 = all slopes in [0, 1]: prelu(m) == max(m, s m).
 // The kernel is VALU-bound (crop unpacking, pooling), and VALU shares the FP32 pipe with the f32 MFMAs.
-template <int S, int C1, int R, int MODE>
+// DBG: the timing-only phase ablations (TRL_FRONT_SKIP, tools/front_ablation.sh); compiled out of the production instantiation.
+template <int S, int C1, int R, int MODE, bool DBG>
 __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__ frames, int nframes, int H, int W,
                                                      const int4* __restrict__ cbox, const int32_t* __restrict__ d_total, int t0,
                                                      const float* __restrict__ w1,
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     const int t = t0 + blockIdx.x;
+    if (!DBG) dbg_skip = 0;                          // a compile-time 0 in production
     // The candidate record and the device-side total are requested together: ONE memory round trip between the launch and the
     // crop's pixel loads (the crop is bound by dependent round trips).  Records past the total are unwritten memory inside the
     // list's allocation; they are read and discarded.
@@ -306,11 +310,10 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
         B1[s] = w1[k * 32 + 16 + l15];
         koff[s] = k + (S * 3 - 9) * (k / 9);
     }
-    const float bias0 = b1[l15], bias1 = b1[16 + l15], sl0 = s1[l15], sl1 = s1[16 + l15];
+    const float bias0 = b1[l15], bias1 = b1[16 + l15];
     __syncthreads();
 
     float* dst = out + (size_t)blockIdx.x * P * P * C1;
-    auto act = [&](float v, float sl) { return MODE == 2 ? vmax_nc(v, sl * v) : (v > 0.f ? v : sl * v); };
     float* const erow = c1_s + (kq * 4) * CLD + l15;             // epilogue lane base: row 4*kq (+q), channel l15
     if (dbg_skip & 2) return;
     for (int p0 = 0; p0 < P; p0 += R) {
@@ -353,14 +356,14 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
             float* ea = erow + mt * (16 * CLD);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                ea[q * CLD] = MODE == 0 ? act(a0[q], sl0) : a0[q];
-                ea[q * CLD + 16] = MODE == 0 ? act(a1[q], sl1) : a1[q];
+                ea[q * CLD] = a0[q];
+                ea[q * CLD + 16] = a1[q];
             }
             if (hasB) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    ea[(64 + q) * CLD] = MODE == 0 ? act(c0[q], sl0) : c0[q];
-                    ea[(64 + q) * CLD + 16] = MODE == 0 ? act(c1[q], sl1) : c1[q];
+                    ea[(64 + q) * CLD] = c0[q];
+                    ea[(64 + q) * CLD + 16] = c1[q];
                 }
             }
         }
@@ -374,21 +377,47 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
             const int pr = idx / (C4 * P);
             const float* src = c1_s + ((2 * pr) * CW + 2 * px) * CLD + 4 * c4;
             float4 best = *reinterpret_cast<const float4*>(src);      // (dy, dx) = (0, 0) always exists
+            float4 low = best;                                        // MODE 0 only: the window's min
             const bool x2 = 2 * px + 2 < CW;                          // ceil mode: the last window is clipped
+            if (x2 && 2 * pr + 2 < nrows) {                           // whole 3x3 window: four three-operand max (min) per channel
+                float4 v[8];
 #pragma unroll
-            for (int dy = 0; dy < 3; dy++) {
-                if (2 * pr + dy >= nrows) break;
+                for (int j = 1; j < 9; j++) v[j - 1] = *reinterpret_cast<const float4*>(src + ((j / 3) * CW + (j % 3)) * CLD);
 #pragma unroll
-                for (int dx = 0; dx < 3; dx++) {
-                    if (dy == 0 && dx == 0) continue;
-                    if (dx == 2 && !x2) continue;
-                    const float4 v = *reinterpret_cast<const float4*>(src + (dy * CW + dx) * CLD);
-                    best.x = vmax_nc(best.x, v.x); best.y = vmax_nc(best.y, v.y); best.z = vmax_nc(best.z, v.z); best.w = vmax_nc(best.w, v.w);
+                for (int j = 0; j < 8; j += 2) {
+                    best.x = vmax3_nc(best.x, v[j].x, v[j + 1].x); best.y = vmax3_nc(best.y, v[j].y, v[j + 1].y);
+                    best.z = vmax3_nc(best.z, v[j].z, v[j + 1].z); best.w = vmax3_nc(best.w, v[j].w, v[j + 1].w);
+                    if (MODE == 0) {
+                        low.x = vmin3_nc(low.x, v[j].x, v[j + 1].x); low.y = vmin3_nc(low.y, v[j].y, v[j + 1].y);
+                        low.z = vmin3_nc(low.z, v[j].z, v[j + 1].z); low.w = vmin3_nc(low.w, v[j].w, v[j + 1].w);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    if (2 * pr + dy >= nrows) break;
+#pragma unroll
+                    for (int dx = 0; dx < 3; dx++) {
+                        if (dy == 0 && dx == 0) continue;
+                        if (dx == 2 && !x2) continue;
+                        const float4 v = *reinterpret_cast<const float4*>(src + (dy * CW + dx) * CLD);
+                        best.x = vmax_nc(best.x, v.x); best.y = vmax_nc(best.y, v.y); best.z = vmax_nc(best.z, v.z); best.w = vmax_nc(best.w, v.w);
+                        if (MODE == 0) { low.x = vmin_nc(low.x, v.x); low.y = vmin_nc(low.y, v.y); low.z = vmin_nc(low.z, v.z); low.w = vmin_nc(low.w, v.w); }
+                    }
                 }
             }
-            if (MODE != 0) {
+            {
                 const float4 sl = *reinterpret_cast<const float4*>(s1 + 4 * c4);
-                best.x = act(best.x, sl.x); best.y = act(best.y, sl.y); best.z = act(best.z, sl.z); best.w = act(best.w, sl.w);
+                if (MODE == 2) {
+                    best.x = vmax_nc(best.x, sl.x * best.x); best.y = vmax_nc(best.y, sl.y * best.y);
+                    best.z = vmax_nc(best.z, sl.z * best.z); best.w = vmax_nc(best.w, sl.w * best.w);
+                } else if (MODE == 1) {
+                    best.x = trl_prelu_med3(best.x, sl.x, trl_prelu_sel(sl.x)); best.y = trl_prelu_med3(best.y, sl.y, trl_prelu_sel(sl.y));
+                    best.z = trl_prelu_med3(best.z, sl.z, trl_prelu_sel(sl.z)); best.w = trl_prelu_med3(best.w, sl.w, trl_prelu_sel(sl.w));
+                } else {
+                    best.x = trl_prelu_pooled(best.x, low.x, sl.x, trl_prelu_sel(sl.x)); best.y = trl_prelu_pooled(best.y, low.y, sl.y, trl_prelu_sel(sl.y));
+                    best.z = trl_prelu_pooled(best.z, low.z, sl.z, trl_prelu_sel(sl.z)); best.w = trl_prelu_pooled(best.w, low.w, sl.w, trl_prelu_sel(sl.w));
+                }
             }
             *reinterpret_cast<float4*>(dst + ((size_t)(p0 + pr) * P + px) * C1 + 4 * c4) = best;
         }
@@ -422,10 +451,11 @@ int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("rnet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->rnet_front_mode < 0) c->rnet_front_mode = slope_mode(sl, 28);
     static const int rr = getenv("TRL_RNET_R") ? atoi(getenv("TRL_RNET_R")) : 4;     // tuning aid: pooled rows per conv1 strip
-#define TRL_RF(RR, MODE) k_mtcnn_front<24, 28, RR, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, reinterpret_cast<const int4*>(c->cb.cbox), \
+#define TRL_RF(RR, MODE, DBG) k_mtcnn_front<24, 28, RR, MODE, DBG><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, reinterpret_cast<const int4*>(c->cb.cbox), \
                                                                        d_total, t0, w->p, b->p, sl->p, d_pool, front_dbg() & 3)
-    if (c->rnet_front_mode == 2) { if (rr == 2) TRL_RF(2, 2); else if (rr == 3) TRL_RF(3, 2); else if (rr == 6) TRL_RF(6, 2); else TRL_RF(4, 2); }
-    else if (c->rnet_front_mode == 1) TRL_RF(4, 1); else TRL_RF(4, 0);
+    if (front_dbg() & 3) { if (c->rnet_front_mode == 2) TRL_RF(4, 2, true); else if (c->rnet_front_mode == 1) TRL_RF(4, 1, true); else TRL_RF(4, 0, true); }
+    else if (c->rnet_front_mode == 2) { if (rr == 2) TRL_RF(2, 2, false); else if (rr == 3) TRL_RF(3, 2, false); else if (rr == 6) TRL_RF(6, 2, false); else TRL_RF(4, 2, false); }
+    else if (c->rnet_front_mode == 1) TRL_RF(4, 1, false); else TRL_RF(4, 0, false);
 #undef TRL_RF
     TRL_LAUNCH_CHECK();
     return TRL_OK;
@@ -440,10 +470,11 @@ int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     if (c->onet_front_mode < 0) c->onet_front_mode = slope_mode(sl, 32);
     static const int orr = getenv("TRL_ONET_R") ? atoi(getenv("TRL_ONET_R")) : 1;   // measured: one pooled row per strip = 49 KB of LDS = three resident
                                                                                    // workgroups per CU: 1.18 vs 1.27 ms (R = 3, two per CU) for the O-Net front
-#define TRL_OF(RR, MODE) k_mtcnn_front<48, 32, RR, MODE><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, reinterpret_cast<const int4*>(c->cb.cbox), \
+#define TRL_OF(RR, MODE, DBG) k_mtcnn_front<48, 32, RR, MODE, DBG><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, reinterpret_cast<const int4*>(c->cb.cbox), \
                                                                        d_total, t0, w->p, b->p, sl->p, d_pool, (front_dbg() >> 2) & 3)
-    if (c->onet_front_mode == 2) { if (orr == 3) TRL_OF(3, 2); else if (orr == 2) TRL_OF(2, 2); else if (orr == 4) TRL_OF(4, 2); else TRL_OF(1, 2); }
-    else if (c->onet_front_mode == 1) TRL_OF(1, 1); else TRL_OF(1, 0);
+    if ((front_dbg() >> 2) & 3) { if (c->onet_front_mode == 2) TRL_OF(1, 2, true); else if (c->onet_front_mode == 1) TRL_OF(1, 1, true); else TRL_OF(1, 0, true); }
+    else if (c->onet_front_mode == 2) { if (orr == 3) TRL_OF(3, 2, false); else if (orr == 2) TRL_OF(2, 2, false); else if (orr == 4) TRL_OF(4, 2, false); else TRL_OF(1, 2, false); }
+    else if (c->onet_front_mode == 1) TRL_OF(1, 1, false); else TRL_OF(1, 0, false);
 #undef TRL_OF
     TRL_LAUNCH_CHECK();
     return TRL_OK;

@@ -78,8 +78,7 @@ struct PnetArgs {
     const float *w1, *w2, *w3, *wh;            // [Kpad][32] zero padded
     const float *b1, *b2, *b3, *bh, *s1, *s2, *s3;
     float thr; int cap;
-    int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); 0 in production
-    int mono1;                                 // all conv1 PReLU slopes >= 0 (pool/PReLU may be swapped)
+    int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); read by the DBG instantiation only
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
     int32_t* xcd_next;                         // per-XCD dynamic tile cursor (8 counters, zeroed before the launch)
     unsigned long long* clk;                   // [0] = earliest workgroup start, [1] = latest workgroup end (device wall clock)
@@ -365,7 +364,6 @@ __global__ __launch_bounds__(256) void k_pyramid0(const uint8_t* __restrict__ fr
 }
 
 // ---- fused PNet --------------------------------------------------------------------------------------
-__device__ __forceinline__ float prelu(float v, float sl) { return v > 0.f ? v : sl * v; }
 
 // A-operand k offsets.  k = 4s+kq walks (tap, channel) of a [pixel][C] LDS tile whose rows are E floats
 // further apart than D consecutive k: offset = k + E*(k/D).  With s a compile-time constant only the step
@@ -377,15 +375,21 @@ __device__ __forceinline__ int koff(int s, int kq, int e1, int e2, int e3) {
     return 4 * s + E * q0 + kq + add;
 }
 
-// UNIT: every PReLU slope of the net lies in [0, 1]; then prelu(v) == max(v, slope*v) exactly (two VALU ops instead
-// of three) and max-pool commutes with PReLU.  Any other weights take the generic instantiation.
-// (vmax_nc / vmax3_nc: trl_common.h)
+// UNIT: no PReLU slope of the net exceeds 1 (negative slopes included); then prelu(v) == max(v, slope*v) exactly (trl_common.h).
+// Weights with a slope above 1 (a trained checkpoint's are unconstrained) take the general instantiation, which costs the same
+// two VALU instructions per value: med3(v, slope*v, +-inf) (trl_prelu_med3).  Both pool conv1 BEFORE its PReLU -- with the
+// window's min next to its max when a conv1 slope is negative (the NEG1 instantiations, trl_prelu_pooled).
 template <bool UNIT>
-__device__ __forceinline__ float prelu_t(float v, float sl) { return UNIT ? vmax_nc(v, sl * v) : prelu(v, sl); }
+__device__ __forceinline__ float prelu_t(float v, float sl, float sel) { return UNIT ? vmax_nc(v, sl * v) : trl_prelu_med3(v, sl, sel); }
+template <bool UNIT>
+__device__ __forceinline__ float prelu_pooled_t(float m, float n, float sl, float sel) {
+    return UNIT ? vmax_nc(m, sl * (sl < 0.f ? n : m)) : trl_prelu_pooled(m, n, sl, sel);
+}
 
-// CLK: diagnostic instantiation that records the launch's execution span on the device wall clock (TRL_PNET_CLOCK=1);
-// the production instantiation carries no instrumentation.
-template <bool UNIT, bool CLK>
+// DBG: diagnostic instantiation -- records the launch's execution span on the device wall clock (TRL_PNET_CLOCK=1) and honours
+// the timing-only phase ablation mask (TRL_PNET_SKIP, tools/pnet_phase_pmc.sh).  The production instantiation (DBG = false)
+// carries neither: no instrumentation and no ablation tests on the hot path.
+template <bool UNIT, bool NEG1, bool DBG>
 __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
@@ -394,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every M-tile index below is SALU work
-    if (CLK && tid == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());   // execution span of the launch, queueing excluded
+    const int dbg_skip = DBG ? a.dbg_skip : 0;                   // a compile-time 0 in production
+    if (DBG && a.clk && tid == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());   // execution span of the launch, queueing excluded
     const int l15 = lane & 15, kq = lane >> 4;      // 16x16x4 operand coordinates
     const int l31 = lane & 31, hh = lane >> 5;      // 32x32x2 operand coordinates
 
@@ -411,6 +416,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     const float bias2 = a.b2[l15], slope2 = a.s2[l15];
     const float bias3 = a.b3[l31], slope3 = a.s3[l31];
     const float biash = a.bh[l15];
+    // general instantiation only: the per-channel med3 selector (+inf: max(v, s v), -inf: min(v, s v)); dead code when UNIT
+    const float sel1 = trl_prelu_sel(slope1), sel2 = trl_prelu_sel(slope2), sel3 = trl_prelu_sel(slope3);
     const f32x4 bias1v = {bias1, bias1, bias1, bias1}, bias2v = {bias2, bias2, bias2, bias2}, biashv = {biash, biash, biash, biash};
 
     // LDS beyond the live tiles is read by zero-weight k padding: it must hold finite values
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         if (tid == 0) cursor = atomicAdd(&a.xcd_next[xcd], 1);   // in flight during phases 0-2, published at the barrier that ends phase 2
 
         // ---- phase 0: prefetched input tile -> RA as [42][42][3] ---------------------------------------------
-        if (!(a.dbg_skip & 16)) {
+        if (!(dbg_skip & 16)) {
 #pragma unroll
         for (int i = 0; i < 7; i++) {        // p < 1792: the 28 pixels past the tile land in RA's tail (finite, never a live operand)
             float* d = RA + 3 * tid + 768 * i;
@@ -526,13 +533,14 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         // sequence spends no VALU on addressing (VALU and f32 MFMA share the FP32 pipe).  Tiles run as pairs of
         // independent accumulator chains; the A operands of pair j+1 are read before the MFMAs of pair j issue
         // and the pool epilogue of pair j-1 runs behind them.
-        if (!(a.dbg_skip & 2)) {
+        if (!(dbg_skip & 2)) {
             const int vy = g.h - 2 - ty * 2 * TS, vx = g.w - 2 - tx * 2 * TS;   // valid conv1 extent inside the tile
-            // max-pool commutes with PReLU when the slope is >= 0 (monotone): pool first, one PReLU per cell.
+            // max-pool commutes with PReLU when the slope is >= 0 (monotone): pool first, one PReLU per cell.  With a negative
+            // slope somewhere the window's min is pooled as well and max_i prelu(v_i) = max(m, s n) (trl_prelu_pooled): still
+            // one PReLU per pooled cell, never four before the pool.
             // Interior tiles (every conv1 pixel of the tile inside the level) also skip the ceil-mode masks.
-            const bool mono = UNIT || a.mono1;
-            const bool fast = mono && vy >= 2 * P1_T && vx >= 2 * P1_T;
-            auto conv1_pool = [&](auto MODE) {                      // 2: interior + monotone, 1: monotone, 0: generic
+            const bool fast = vy >= 2 * P1_T && vx >= 2 * P1_T;
+            auto conv1_pool = [&](auto MODE) {                      // 2: interior + monotone, 1: monotone, 4 / 3: the same with a negative slope
                 constexpr int kMode = decltype(MODE)::value;
                 float xs[2][14];
                 f32x4 acc[2][2];
@@ -553,19 +561,20 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     const bool c0 = 8 * pg + 2 * kq < vx, c1 = 8 * pg + 2 * kq + 1 < vx;
                     if (kMode == 2) {
                         const float m = vmax_nc(vmax3_nc(v[0], v[1], v[2]), v[3]);
-                        outv = prelu_t<UNIT>(m, slope1);
-                    } else if (kMode == 1) {                          // ceil-mode window clipped by the level edge
-                        const float ninf = -__builtin_inff();
-                        const float a1 = (r0 && c1) ? v[1] : ninf, a2 = (r1 && c0) ? v[2] : ninf, a3 = (r1 && c1) ? v[3] : ninf;
-                        const float m = fmaxf(fmaxf(v[0], a1), fmaxf(a2, a3));
-                        outv = (r0 && c0) ? prelu_t<UNIT>(m, slope1) : 0.f;
-                    } else {
-                        const float v0 = prelu(v[0], slope1), v1 = prelu(v[1], slope1), v2 = prelu(v[2], slope1), v3 = prelu(v[3], slope1);
-                        float m = v0;                                 // (dy,dx) = (0,0) is valid whenever the cell is
-                        m = (r0 && c1 && v1 > m) ? v1 : m;
-                        m = (r1 && c0 && v2 > m) ? v2 : m;
-                        m = (r1 && c1 && v3 > m) ? v3 : m;
-                        outv = (r0 && c0) ? m : 0.f;
+                        outv = prelu_t<UNIT>(m, slope1, sel1);
+                    } else if (kMode == 4) {
+                        const float m = vmax_nc(vmax3_nc(v[0], v[1], v[2]), v[3]), n = vmin_nc(vmin3_nc(v[0], v[1], v[2]), v[3]);
+                        outv = prelu_pooled_t<UNIT>(m, n, slope1, sel1);
+                    } else {                                          // ceil-mode window clipped by the level edge
+                        const float ninf = -__builtin_inff();         // (dy,dx) = (0,0) is valid whenever the cell is
+                        const bool k1 = r0 && c1, k2 = r1 && c0, k3 = r1 && c1;
+                        const float m = fmaxf(fmaxf(v[0], k1 ? v[1] : ninf), fmaxf(k2 ? v[2] : ninf, k3 ? v[3] : ninf));
+                        if (kMode == 1) {
+                            outv = (r0 && c0) ? prelu_t<UNIT>(m, slope1, sel1) : 0.f;
+                        } else {
+                            const float n = fminf(fminf(v[0], k1 ? v[1] : -ninf), fminf(k2 ? v[2] : -ninf, k3 ? v[3] : -ninf));
+                            outv = (r0 && c0) ? prelu_pooled_t<UNIT>(m, n, slope1, sel1) : 0.f;
+                        }
                     }
                     if (l15 < 10) RB[c1_lp + i * (4 * P1_T * 10) + pg * 40] = outv;
                 };
@@ -592,14 +601,13 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 }
                 pool_store(acc[0][0], 24);
             };
-            if (fast) conv1_pool(std::integral_constant<int, 2>{});
-            else if (mono) conv1_pool(std::integral_constant<int, 1>{});
-            else conv1_pool(std::integral_constant<int, 0>{});
+            if (fast) conv1_pool(std::integral_constant<int, NEG1 ? 4 : 2>{});
+            else conv1_pool(std::integral_constant<int, NEG1 ? 3 : 1>{});
         }
         __syncthreads();
 
         // ---- phase 2: conv2 + PReLU -> RA as [324][17] ---------------------------------------------------------
-        if (!(a.dbg_skip & 4)) {
+        if (!(dbg_skip & 4)) {
             // 21 M-tiles of 16 rows (last one 4 rows); wave w takes pairs (w, w+4), (w+8, w+12), (w+16, w+20).
             // RA (the input tile) is dead since the barrier above, so the epilogue may overwrite it.
             // The A operands of pair j+1 are requested right after the MFMAs of pair j are issued, so their LDS
@@ -652,9 +660,9 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int ra = mtA * 16 + kq * 4 + q;
-                    if (hasA && ra < 324) RA[ra * C2_LD + l15] = prelu_t<UNIT>(accA[q], slope2);
+                    if (hasA && ra < 324) RA[ra * C2_LD + l15] = prelu_t<UNIT>(accA[q], slope2, sel2);
                     const int rb = mtB * 16 + kq * 4 + q;
-                    if (hasB && rb < 324) RA[rb * C2_LD + l15] = prelu_t<UNIT>(accB[q], slope2);
+                    if (hasB && rb < 324) RA[rb * C2_LD + l15] = prelu_t<UNIT>(accB[q], slope2, sel2);
                 }
             }
         }
@@ -663,10 +671,10 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 
         // next tile's input: global loads into registers only (RA is still read by phase 3)
         tile_nxt = __builtin_amdgcn_readfirstlane(next_tile_s);
-        if (tile_nxt < t_end) { nxt = decode(tile_nxt); if (!(a.dbg_skip & 1)) issue_input(nxt); }
+        if (tile_nxt < t_end) { nxt = decode(tile_nxt); if (!(dbg_skip & 1)) issue_input(nxt); }
 
         // ---- phase 3: conv3 + PReLU -> per-wave staging -> heads -> candidates -------------------------------
-        if (!(a.dbg_skip & 8)) {
+        if (!(dbg_skip & 8)) {
             float* ST = RB + wave * 32 * ST_LD;
             const float fscale = g.scale;
 #pragma unroll 1
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-                    ST[row * ST_LD + l31] = prelu_t<UNIT>(acc[q], slope3);
+                    ST[row * ST_LD + l31] = prelu_t<UNIT>(acc[q], slope3, sel3);
                 }
                 __builtin_amdgcn_wave_barrier();
                 // heads: two 16-row M-tiles, K = 32
@@ -727,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     if (oy < g.oh && ox < g.ow) {
                         const float* hv = HS + lane * 9;
                         const float p = trl_softmax2_p1(hv[0], hv[1]);
-                        if (p >= a.thr && !(a.dbg_skip & 32)) {      // (bit 32: timing-only ablations emit no candidates)
+                        if (p >= a.thr && !(dbg_skip & 32)) {      // (bit 32: timing-only ablations emit no candidates)
                             const int seg = f * a.L + l;
                             const int sl = atomicAdd(&a.lvl_cnt[seg], 1);
                             if (sl < a.cap) {
@@ -751,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         }
         __syncthreads();   // RA / RB are rewritten by the next tile
     }
-    if (CLK && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
+    if (DBG && a.clk && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
 
 }  // namespace
@@ -775,7 +783,7 @@ int trl_pnet_prepare(trl_ctx* c) {
         const DevV* v = trl_v(c, n);
         std::vector<float> h(v->n);
         TRL_HIP(hipMemcpy(h.data(), v->p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
-        for (float x : h) if (!(x >= 0.f && x <= 1.f)) c->pnet_unit = 0;
+        for (float x : h) if (!(x <= 1.f)) c->pnet_unit = 0;
     }
     return TRL_OK;
 }
@@ -849,7 +857,6 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
     a.s1 = trl_v(c, "pnet.prelu1")->p; a.s2 = trl_v(c, "pnet.prelu2")->p; a.s3 = trl_v(c, "pnet.prelu3")->p;
     a.thr = c->cfg.thr0; a.cap = c->cfg.cap_level;
     { const char* e = getenv("TRL_PNET_SKIP"); a.dbg_skip = e ? atoi(e) : 0; }
-    a.mono1 = c->pnet_mono1;
     a.lvl_cnt = c->cb.lvl_cnt; a.lvl_rec = c->cb.lvl_rec; a.flags = c->cb.flags;
     a.clk = c->pnet_clk;
     a.xcd_next = c->pnet_cursor;
@@ -1192,17 +1199,16 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     }
     if (ev) TRL_HIP(hipEventRecord(ev[2], s));   // the event pair brackets the kernel alone (HIP events on the launch's stream)
     static const int xlds = getenv("TRL_PNET_XLDS") ? atoi(getenv("TRL_PNET_XLDS")) : 0;   // experiment: unused dynamic LDS, lowers the resident workgroups per CU
-    if (xlds > 0) {
-        (void)hipFuncSetAttribute((const void*)k_pnet_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, xlds);
-        (void)hipFuncSetAttribute((const void*)k_pnet_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, xlds);
-    }
-    if (c->pnet_clk) {
-        if (c->pnet_unit) k_pnet_fused<true, true><<<grid, 256, xlds, s>>>(a);
-        else k_pnet_fused<false, true><<<grid, 256, xlds, s>>>(a);
-    } else {
-        if (c->pnet_unit) k_pnet_fused<true, false><<<grid, 256, xlds, s>>>(a);
-        else k_pnet_fused<false, false><<<grid, 256, xlds, s>>>(a);
-    }
+    // instantiation: slopes all <= 1 or not, a negative conv1 slope or not, diagnostics (TRL_PNET_CLOCK / TRL_PNET_SKIP) or not
+    const bool dbg = c->pnet_clk || a.dbg_skip;
+    auto launch = [&](auto kern) {
+        if (xlds > 0) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, xlds);
+        kern<<<grid, 256, xlds, s>>>(a);
+    };
+#define TRL_PK(U, N) do { if (dbg) launch(k_pnet_fused<U, N, true>); else launch(k_pnet_fused<U, N, false>); } while (0)
+    if (c->pnet_unit) { if (c->pnet_mono1) TRL_PK(true, false); else TRL_PK(true, true); }
+    else { if (c->pnet_mono1) TRL_PK(false, false); else TRL_PK(false, true); }
+#undef TRL_PK
     TRL_LAUNCH_CHECK();
     if (ev) TRL_HIP(hipEventRecord(ev[3], s));
     return TRL_OK;

@@ -54,6 +54,14 @@ class Engine:
         self._blob = blob
         _lib.check(self.lib.trl_load_weights(self._h, blob, len(blob)))
 
+    def clone(self) -> "Engine":
+        """A second context on the same device with the same weights and configuration (its own workspaces: contexts are the
+        unit of concurrency -- one batch in flight each)."""
+        c = self.cfg
+        return Engine(self._blob, device=c.device, pnet_mode=c.pnet_mode, cap_level=c.cap_level, cap_frame=c.cap_frame,
+                      min_face_size=c.min_face_size, thresholds=(c.thr0, c.thr1, c.thr2), factor=c.factor, max_faces=c.max_faces,
+                      embed_mode=c.embed_mode, embed_precision=c.embed_precision)
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.trl_destroy(self._h)
@@ -111,6 +119,48 @@ class Engine:
                "emb": torch.empty((n, 512), dtype=torch.float32, device=d)}
         _lib.check(self.lib.trl_detect_embed(self._h, _ptr(fr), n, H, W, _ptr(out["box"]), _ptr(out["prob"]), _ptr(out["rect"]),
                                              _ptr(out["valid"]), _ptr(out["emb"]), self._stream()))
+        return out
+
+    # detect_embed / detect_crop split into "queue" and "finish" (trl_detect_embed_begin / _end): one host thread can keep
+    # several engines busy, each on its own stream, without a thread per engine (pipeline.detect_embed_overlapped)
+    def detect_embed_begin(self, frames, crop: bool = False, faces: torch.Tensor | None = None, valid: torch.Tensor | None = None):
+        """Queue detect_embed (or, with ``crop=True``, detect_crop) on the current stream and return at once; the outputs are
+        valid after :meth:`detect_embed_end`.  An engine holds one call in flight.  ``faces`` / ``valid`` (optional, crop mode):
+        caller-owned contiguous destination buffers -- a slot of a ring whose neighbours hold other batches' crops, so several
+        batches can be embedded in one call without a copy (pipeline.detect_embed_overlapped)."""
+        fr = self._frames(frames)
+        n, H, W, _ = fr.shape
+        d = self.device
+        out = {"box": torch.empty((n, 4), dtype=torch.float32, device=d), "prob": torch.empty((n,), dtype=torch.float32, device=d),
+               "rect": torch.empty((n, 4), dtype=torch.int32, device=d)}
+        if valid is None:
+            valid = torch.empty((n,), dtype=torch.uint8, device=d)
+        elif valid.shape != (n,) or valid.dtype != torch.uint8 or not valid.is_contiguous():
+            raise ValueError("valid must be a contiguous uint8 (n,) tensor")
+        out["valid"] = valid
+        if crop:
+            S = 80 if self.cfg.embed_mode == 0 else 160
+            if faces is None:
+                faces = torch.empty((n, S, S, 3), dtype=torch.float32, device=d)
+            elif faces.shape != (n, S, S, 3) or faces.dtype != torch.float32 or not faces.is_contiguous():
+                raise ValueError(f"faces must be a contiguous float32 ({n}, {S}, {S}, 3) tensor")
+            out["faces"] = faces
+            _lib.check(self.lib.trl_detect_crop_begin(self._h, _ptr(fr), n, H, W, _ptr(out["box"]), _ptr(out["prob"]), _ptr(out["rect"]),
+                                                      _ptr(out["valid"]), _ptr(out["faces"]), self._stream()))
+        else:
+            out["emb"] = torch.empty((n, 512), dtype=torch.float32, device=d)
+            _lib.check(self.lib.trl_detect_embed_begin(self._h, _ptr(fr), n, H, W, _ptr(out["box"]), _ptr(out["prob"]), _ptr(out["rect"]),
+                                                       _ptr(out["valid"]), _ptr(out["emb"]), self._stream()))
+        self._pending = (out, fr)            # the frame tensor must outlive the queued kernels
+        return out
+
+    def detect_embed_end(self):
+        """Finish the call queued by :meth:`detect_embed_begin`: the one host synchronisation, the capacity check and (rarely) the re-run."""
+        out, _fr = self._pending
+        try:
+            _lib.check(self.lib.trl_detect_embed_end(self._h))
+        finally:
+            self._pending = None
         return out
 
     # the two halves of detect_embed: callers that embed the faces of several batches in ONE embedder call (pipeline.py)
@@ -185,6 +235,12 @@ class Engine:
         k = C.c_int()
         _lib.check(self.lib.trl_debug_batch_capacity(self._h, float(t2_per_frame), float(t3_per_frame), C.byref(k)))
         return k.value
+
+    def stage_totals(self):
+        """(boxes that entered R-Net, boxes that entered O-Net) over the whole batch of the last call."""
+        t = (C.c_int32 * 2)()
+        _lib.check(self.lib.trl_debug_stage_totals(self._h, t))
+        return int(t[0]), int(t[1])
 
     def poison_workspaces(self, byte: int = 0xFF):
         """Test hook: fill the activation workspaces with a byte pattern (0xFF = NaNs)."""

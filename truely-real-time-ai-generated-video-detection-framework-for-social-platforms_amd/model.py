@@ -27,11 +27,12 @@ BATCH = 32   # sampled frames per device call inside run(): the window holds BAT
 
 
 def analyze_video(frames, fps: int = 30, frame_count: int | None = None, engine: Engine | None = None,
-                  batch: int | None = None, engines=None, embed_group: int = 1) -> dict:
+                  batch: int | None = None, engines=None, embed_group: int = 1, embed_engine: Engine | None = None) -> dict:
     """Batched model.py:42-75,86-95 over already-sampled frames ``(n, H, W, 3)`` uint8 BGR
     (numpy or a device tensor).  ``frame_count`` = frames decoded (defaults to n*step).
-    ``engines`` (a list of >= 2 contexts on the same GPU) keeps that many batches in flight (pipeline.py);
-    ``embed_group`` > 1 embeds the faces of that many batches per embedder call (same results, fewer and larger launches)."""
+    ``engines`` (a list of >= 2 contexts on the same GPU) keeps that many batches in flight, driven by this one thread
+    (pipeline.detect_embed_overlapped); ``embed_group`` > 1 embeds the faces of that many consecutive batches per embedder call
+    on ``embed_engine`` (a further context, created on demand) -- same results, fewer and larger launches."""
     eng = engine or (engines[0] if engines else default_engine())
     n = int(frames.shape[0])
     step = max(1, int(fps / 7))
@@ -39,8 +40,9 @@ def analyze_video(frames, fps: int = 30, frame_count: int | None = None, engine:
         frame_count = n * step
     bs = batch or n
     if engines and len(engines) > 1:
-        from .pipeline import detect_embed_pipelined
-        outs = detect_embed_pipelined(engines, [frames[i:i + bs] for i in range(0, n, bs)], embed_group=embed_group)
+        from .pipeline import detect_embed_overlapped
+        outs = detect_embed_overlapped(engines, [frames[i:i + bs] for i in range(0, n, bs)], embed_group=embed_group,
+                                       embed_engine=embed_engine)
     else:
         from .pipeline import detect_embed_grouped
         outs = detect_embed_grouped(eng, [frames[i:i + bs] for i in range(0, n, bs)], embed_group)

@@ -40,6 +40,166 @@ def detect_embed_grouped(engine: Engine, batches: Sequence, embed_group: int = 1
     return outs
 
 
+def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Callable[[int, dict], None] | None = None,
+                            streams=None, embed_group: int = 1, embed_engine: Engine | None = None, n_batches: int | None = None,
+                            on_detect: Callable[[int, int], None] | None = None) -> List[dict]:
+    """Batches in flight driven by ONE host thread.  Batch i is queued on ``engines[i % F]`` (``trl_detect_embed_begin`` /
+    ``trl_detect_crop_begin``: return without synchronising) on that engine's stream and finished (``trl_detect_embed_end``)
+    right before the engine is needed again, so F batches are in flight and no thread per context is needed.
+
+    ``embed_group`` = G > 1: the embedder is decoupled from the batches.  The cascades write their crops into consecutive slots
+    of a ring; every G consecutive batches (in batch order, whichever engine produced them) are embedded by ONE
+    ``trl_facenet_embed_masked`` call on ``embed_engine``'s own stream while the next batches are being detected.
+    InceptionResnetV1 at the reference's 80x80 crops is ~100 small dependent launches whose fixed cost amortises over the faces
+    of a call: 2.22 ms per 256 faces at 256 per call, 1.78 ms (42.7 % of the f32-MFMA peak) at 768.  Every output element is the
+    same accumulation chain whatever the grouping: results are bit-identical to per-batch ``detect_embed``.
+
+    ``batches``: a sequence, or a callable ``(i, j) -> batch`` with ``n_batches`` (the bench's NV12 uploader prefetches per engine).
+    ``on_detect(i, j)`` is called when batch i's cascade has finished on engine j (timing hooks); ``on_result(i, out)`` in batch
+    order once the batch's embeddings exist.  Returns the per-batch results in batch order."""
+    F = len(engines)
+    if F == 0:
+        raise ValueError("need at least one engine")
+    if callable(batches):
+        get, K = batches, int(n_batches)
+    else:
+        seq = list(batches)
+        get, K = (lambda i, j: seq[i]), len(seq)
+    G = max(1, int(embed_group))
+    dev = engines[0].device
+    streams = streams or [torch.cuda.Stream(dev) for _ in range(F)]
+    outs: List[dict] = []
+    inflight = [None] * F                                # batch index queued on engine j
+
+    def deliver(i, out):
+        if on_result:
+            on_result(i, out)
+        outs.append(out)
+
+    if G == 1:
+        def finish(j):
+            i = inflight[j]
+            with torch.cuda.stream(streams[j]):
+                out = engines[j].detect_embed_end()      # synchronises stream j: the tensors are safe to use on any stream
+            inflight[j] = None
+            if on_detect:
+                on_detect(i, j)
+            deliver(i, out)
+
+        for i in range(K):
+            j = i % F
+            if inflight[j] is not None:
+                finish(j)
+            with torch.cuda.stream(streams[j]):
+                engines[j].detect_embed_begin(get(i, j))
+            inflight[j] = i
+        for k in range(K, K + F):                        # drain in batch order
+            if inflight[k % F] is not None:
+                finish(k % F)
+        return outs
+
+    # ---- decoupled, grouped embedder ----------------------------------------------------------------------------------
+    emb_eng = embed_engine or engines[0].clone()         # its own context (workspace): the embedder overlaps every cascade
+    es = torch.cuda.Stream(dev)
+    S = 80 if engines[0].cfg.embed_mode == 0 else 160
+    R = G * ((2 * G + F + G - 1) // G)                   # slots: F being written, G being collected, G being embedded; a multiple
+                                                         # of G so that a group never straddles the ring's end
+    ring = {"n": 0, "faces": None, "valid": None}
+    group: List[tuple] = []                              # (batch index, out) collected for the next embedder call, consecutive slots
+    pending: List[tuple] = []                            # (event, emb, [(i, out), ...]) embedder calls in flight, oldest first
+
+    def slot_views(i, n):
+        if ring["faces"] is None:
+            ring["n"] = n
+            ring["faces"] = torch.empty((R, n, S, S, 3), dtype=torch.float32, device=dev)
+            ring["valid"] = torch.empty((R, n), dtype=torch.uint8, device=dev)
+        if n > ring["n"]:
+            raise ValueError("batches must not grow after the first one")
+        k = i % R
+        return ring["faces"][k, :n], ring["valid"][k, :n]
+
+    def retire(block_for: int | None = None):
+        """Deliver finished embedder calls (oldest first); with ``block_for`` = a batch index, wait for every call that still
+        reads the ring slot that batch is about to overwrite."""
+        while pending:
+            ev, emb, members = pending[0]
+            must = block_for is not None and members[0][0] <= block_for - R
+            if not (must or ev.query()):
+                break
+            ev.synchronize()
+            o = 0
+            for i, out in members:
+                n = out["valid"].shape[0]
+                out["emb"] = emb[o:o + n]
+                o += n
+                out["valid"] = out["valid"].clone()      # the ring slot is reused
+                del out["faces"]
+                deliver(i, out)
+            pending.pop(0)
+
+    def flush_group():
+        if not group:
+            return
+        i0, n_full = group[0][0], ring["n"]
+        k0 = i0 % R
+        cnt = sum(out["valid"].shape[0] for _, out in group)
+        if len(group) == 1:
+            faces, valid = group[0][1]["faces"], group[0][1]["valid"]
+        else:                                            # consecutive full slots (+ an optional short last one): one contiguous view
+            faces = ring["faces"].view(R * n_full, S, S, 3)[k0 * n_full:k0 * n_full + cnt]
+            valid = ring["valid"].view(R * n_full)[k0 * n_full:k0 * n_full + cnt]
+        with torch.cuda.stream(es):                      # the crops are complete: their cascades were synchronised by _end
+            emb = emb_eng.embed_faces(faces, valid)      # queues ~100 launches and returns
+            ev = torch.cuda.Event()
+            ev.record(es)
+        pending.append((ev, emb, list(group)))
+        group.clear()
+
+    def finish(j):
+        i = inflight[j]
+        with torch.cuda.stream(streams[j]):
+            out = engines[j].detect_embed_end()
+        inflight[j] = None
+        if on_detect:
+            on_detect(i, j)
+        done[i] = out
+
+    done: dict = {}                                      # cascades finished out of batch order wait here
+    nxt = [0]                                            # next batch index to join a group
+
+    def collect():
+        while nxt[0] in done:
+            i = nxt[0]
+            out = done.pop(i)
+            n = out["valid"].shape[0]
+            group.append((i, out))
+            nxt[0] += 1
+            short = n < ring["n"]
+            wraps = (i + 1) % R == 0                     # the next slot is not adjacent in memory
+            if len(group) == G or short or wraps or i == K - 1:
+                flush_group()
+
+    for i in range(K):
+        j = i % F
+        if inflight[j] is not None:
+            finish(j)
+            collect()
+        retire(block_for=i)
+        b = get(i, j)
+        fv, vv = slot_views(i, int(b.shape[0]))
+        with torch.cuda.stream(streams[j]):
+            engines[j].detect_embed_begin(b, crop=True, faces=fv, valid=vv)
+        inflight[j] = i
+    for k in range(K, K + F):
+        if inflight[k % F] is not None:
+            finish(k % F)
+            collect()
+    flush_group()
+    while pending:
+        retire(block_for=pending[0][2][0][0] + R)        # wait for the oldest call
+    return outs
+
+
 def detect_embed_pipelined(engines: Sequence[Engine], batches: Iterable, on_result: Callable[[int, dict], None] | None = None,
                            embed_group: int = 1) -> List[dict]:
     """``engines[j]`` processes batches j, j+F, j+2F, ... (F = len(engines)) on its own stream and thread; with

@@ -294,17 +294,28 @@ def synthetic_state_dicts(seed: int = 0, calibration: Mapping[str, float] | None
     return nets["pnet"], nets["rnet"], nets["onet"], fn
 
 
-def generalise_prelu(sds):
+# Face-logit offsets that give the generalised slopes the SAME candidate mix as the seeded ones on the bench clip (R-Net / O-Net
+# boxes per 256 frames), found by tools/calibrate_general_prelu.py on the GPU: without them the changed nets pass twice as many
+# candidates on, and the `--prelu general` bench line measures that extra work, not the kernels' general-slope instantiations.
+GENERAL_PRELU_MATCH = {"pnet": -0.077562, "rnet": -0.196295, "onet": -1.328416}
+
+
+def generalise_prelu(sds, match=None):
     """In place: give the seeded MTCNN PReLUs slopes a trained checkpoint may have -- some above 1, some negative --
-    so the kernels' general instantiations run (k_pnet_fused<false>, PReLU-before-pool front kernels) instead of
-    the `max(v, s*v)` / pool-first shortcuts that slopes in [0, 1] allow.  bench.py --prelu general times that."""
+    so the kernels' general instantiations run (k_pnet_fused<false, true>: med3 PReLU, min+max pooling; front kernels MODE 0)
+    instead of the `max(v, s*v)` forms that slopes in [0, 1] allow.  bench.py --prelu general times that.  ``match`` (default
+    GENERAL_PRELU_MATCH) shifts each net's face logit so the candidate counts stay those of the seeded slopes."""
     pnet, rnet, onet = sds[0], sds[1], sds[2]
-    for net in (pnet, rnet, onet):
+    match = GENERAL_PRELU_MATCH if match is None else match
+    for name, net, cls in (("pnet", pnet, "conv4_1"), ("rnet", rnet, "dense5_1"), ("onet", onet, "dense6_1")):
         for key in [k for k in net if k.startswith("prelu") and k.endswith(".weight")]:
             w = np.array(net[key], np.float32, copy=True)
             w[::5] = np.float32(1.25)
             w[2::7] = np.float32(-0.2)
             net[key] = w
+        b = np.array(net[f"{cls}.bias"], np.float32, copy=True)
+        b[1] += np.float32(match.get(name, 0.0))
+        net[f"{cls}.bias"] = b
     return sds
 
 
