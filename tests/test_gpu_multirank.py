@@ -53,6 +53,23 @@ def test_world2_streams_mode(engine):
         assert r["config"]["scores"][s] == engine.drift_score(out["emb"], out["valid"], n * 4, 30)["score"]
 
 
+def test_config3_concurrent_ingest_rehearsal(engine):
+    """BASELINE configs[3] as worded -- "8-video concurrent INGEST, frame-sharded across GPUs" -- rehearsed with two rank processes on
+    this one card: every rank takes ITS OWN clip as host NV12 (what a decoder hands over), uploads it through pinned memory on a
+    copy stream, converts it on the device (trl_ingest_nv12) and scores it; no data-path collective.  Each rank's score must be
+    the score a single process gets for that clip through the same NV12 round trip."""
+    from truely_amd.ingest import bgr_to_nv12
+    n = 4
+    r = _bench("--gpus", "2", "--backend", "gloo", "--mode", "streams", "--ingest", "nv12", "--batch", str(n), "--steps", "3",
+               "--warmup", "1", "--no-cpu-baseline")
+    assert r["n_gpus"] == 2 and r["config"]["mode"] == "streams" and r["config"]["ingest"] == "nv12" and len(r["config"]["scores"]) == 2
+    for s in (0, 1):
+        fr = truely_amd.synthetic.synthetic_frames(n, 720, 1280, seed=s)
+        bgr = engine.ingest_nv12(bgr_to_nv12(fr), 720, 1280, 1)            # BT.601 round trip: what the rank's detector saw
+        out = engine.detect_embed(bgr)
+        assert r["config"]["scores"][s] == engine.drift_score(out["emb"], out["valid"], n * 4, 30)["score"], s
+
+
 def test_rccl_needs_as_many_gpus_as_ranks():
     """On this one-GPU box the RCCL launch must fail loudly instead of silently running one rank."""
     if torch.cuda.device_count() >= 2:

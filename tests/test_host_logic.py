@@ -336,3 +336,187 @@ def test_y4m_reader_repacks_planes_to_nv12(tmp_path):
         r = str(tmp_path / "bad.y4m")
         open(r, "wb").write(bad + b"FRAME\n" + bytes(100))
         assert video_io.open_reader(r) is None
+
+
+def _mp4_with(stsz_payload=None, stco_payload=None, stsc_payload=None, moof=None, trex=True):
+    """A minimal H.264 mp4 whose sample tables (or fragments) are supplied by the caller: the probe's hostile-input tests."""
+    import struct as st
+    sps, pps = bytes([0x67, 100, 0, 31, 0xAC]), bytes([0x68, 0xEE, 0x3C, 0x80])
+    avcc = _box(b"avcC", bytes([1, 100, 0, 31, 0xFF, 0xE1]) + st.pack(">H", len(sps)) + sps + bytes([1]) + st.pack(">H", len(pps)) + pps)
+    entry_body = bytes(6) + st.pack(">H", 1) + bytes(16) + st.pack(">HH", 320, 180) + bytes(50) + avcc
+    stsd = _box(b"stsd", st.pack(">II", 0, 1) + st.pack(">I4s", 8 + len(entry_body), b"avc1") + entry_body)
+    stsc = _box(b"stsc", stsc_payload if stsc_payload is not None else st.pack(">II", 0, 1) + st.pack(">III", 1, 5, 1))
+    stsz = _box(b"stsz", stsz_payload if stsz_payload is not None else st.pack(">III", 0, 0, 0))
+    stco = _box(b"stco", stco_payload if stco_payload is not None else st.pack(">II", 0, 1) + st.pack(">I", 4096))
+    stbl = _box(b"stbl", stsd + stsc + stsz + stco)
+    hdlr = _box(b"hdlr", st.pack(">II4s", 0, 0, b"vide") + bytes(13))
+    mdhd = _box(b"mdhd", st.pack(">IIIII", 0, 0, 0, 12800, 2560) + bytes(4))
+    mdia = _box(b"mdia", mdhd + hdlr + _box(b"minf", stbl))
+    tkhd = _box(b"tkhd", st.pack(">IIII", 0, 0, 0, 7) + bytes(68))
+    mvex = _box(b"mvex", _box(b"trex", st.pack(">IIIIII", 0, 7, 1, 512, 0, 0))) if trex else b""
+    moov = _box(b"moov", _box(b"trak", tkhd + mdia) + mvex)
+    return _box(b"ftyp", b"isom" + bytes(4)) + moov + (moof or b"")
+
+
+def test_mp4_probe_rejects_hostile_counts(tmp_path):
+    """The 32-bit counts of stsz / stco / stsc / trun come straight from an upload (model.run describes every clip the decoder
+    rejects: video_io.describe -> mp4probe.probe).  A count the box cannot hold must be refused at once -- not turned into a
+    34 GB list or a 4e9-iteration loop inside the single-worker analysis service."""
+    import struct as st
+    import time
+    from truely_amd import mp4probe
+    big = 0xFFFFFFFF
+    traf = lambda trun: _box(b"moof", _box(b"traf", _box(b"tfhd", st.pack(">II", 0x020000, 7)) + trun))   # noqa: E731
+    cases = {
+        "stsz_uniform": _mp4_with(stsz_payload=st.pack(">III", 0, 1000, big)),                  # uniform size, 4e9 samples
+        "stsz_table": _mp4_with(stsz_payload=st.pack(">III", 0, 0, big) + bytes(16)),           # table count past the box
+        "stco": _mp4_with(stsz_payload=st.pack(">III", 0, 0, 2) + st.pack(">2I", 10, 10), stco_payload=st.pack(">II", 0, big)),
+        "stsc": _mp4_with(stsz_payload=st.pack(">III", 0, 0, 2) + st.pack(">2I", 10, 10), stsc_payload=st.pack(">II", 0, big)),
+        "trun_no_fields": _mp4_with(moof=traf(_box(b"trun", st.pack(">II", 0, big)))),           # flags = 0: nothing per sample
+        "trun_sizes": _mp4_with(moof=traf(_box(b"trun", st.pack(">II", 0x200, big) + bytes(64)))),
+        "trun_default_size": _mp4_with(moof=_box(b"moof", _box(b"traf", _box(b"tfhd", st.pack(">III", 0x020010, 7, 4096)) +
+                                                          _box(b"trun", st.pack(">II", 0, 9_000_000))))),
+    }
+    for name, blob in cases.items():
+        p = tmp_path / f"{name}.mp4"
+        p.write_bytes(blob)
+        t0 = time.time()
+        with pytest.raises(mp4probe.Mp4Error):
+            mp4probe.probe(str(p))
+        assert video_io.describe(str(p)) == "unknown container", name       # what model.run prints for it
+        assert time.time() - t0 < 1.0, name
+    # sane neighbours still parse: a uniform-size table, and a fragment run that relies on the default sample size
+    ok = tmp_path / "uniform.mp4"
+    ok.write_bytes(_mp4_with(stsz_payload=st.pack(">III", 0, 100, 5)) + bytes(5000))
+    i = mp4probe.probe(str(ok))
+    assert i.frame_count == 5 and i.sample_ranges == [(4096 + 100 * k, 100) for k in range(5)]
+    frag = tmp_path / "frag.mp4"
+    frag.write_bytes(_mp4_with(moof=_box(b"moof", _box(b"traf", _box(b"tfhd", st.pack(">III", 0x020010, 7, 64)) +
+                                                   _box(b"trun", st.pack(">II", 0, 3))))) + bytes(256))
+    j = mp4probe.probe(str(frag))
+    assert j.fragmented and j.frame_count == 3 and [s for _, s in j.sample_ranges] == [64, 64, 64]
+
+
+def test_mjpeg_avi_sink_and_source(tmp_path):
+    """Without OpenCV the annotated output is Motion-JPEG in an AVI container (bounded size, a standard file), whatever the
+    output path is called; the same container is the one compressed INPUT this build decodes itself.  RIFF structure, header
+    fields, index, lossy-but-close frames, odd-sized chunks padded, and the `.trlv` escape hatch of the tests."""
+    import struct as st
+    fr = truely_amd.synthetic.synthetic_frames(6, 90, 160, seed=4)
+    p = str(tmp_path / "video_output.mp4")                             # the name server.py gives it (H.264 needs OpenCV)
+    w = video_io.open_writer(p, 30, (160, 90))
+    assert isinstance(w, video_io.AviMjpegWriter)
+    for f in fr:
+        w.write(f)
+    w.release()
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI " and st.unpack_from("<I", raw, 4)[0] == len(raw) - 8
+    assert len(raw) < fr.nbytes // 4                                   # bounded: far below the raw frames
+    movi = raw.index(b"movi")
+    assert raw[movi - 8:movi - 4] == b"LIST"
+    (movi_bytes,) = st.unpack_from("<I", raw, movi - 4)
+    idx = movi + movi_bytes - 4 + 4                                    # list payload starts at 'movi'
+    assert raw[idx:idx + 4] == b"idx1" and st.unpack_from("<I", raw, idx + 4)[0] == 16 * 6
+    for k in range(6):                                                  # every index entry points at a JPEG (SOI marker)
+        cid, _fl, off, size = st.unpack_from("<4sIII", raw, idx + 8 + 16 * k)
+        assert cid == b"00dc" and raw[movi + off:movi + off + 4] == b"00dc" and raw[movi + off + 8:movi + off + 10] == b"\xff\xd8"
+    rd, fps, W, H = video_io.open_reader(p)
+    assert isinstance(rd, video_io.AviMjpegReader) and (fps, W, H, rd.n) == (30, 160, 90, 6)
+    for k in range(6):
+        ok, g = rd.read()
+        assert ok and g.shape == (90, 160, 3)
+        mse = ((g.astype(np.float64) - fr[k]) ** 2).mean()
+        assert 10 * np.log10(255.0 ** 2 / mse) > 30.0                  # BGR order kept (a swapped channel would be ~10 dB)
+    assert rd.read() == (False, None)
+    rd.release()
+    assert isinstance(video_io.open_writer(str(tmp_path / "o.trlv"), 30, (160, 90)), video_io.RawWriter)
+    bad = tmp_path / "bad.avi"
+    bad.write_bytes(raw[:200])                                          # truncated: no frames -> "cannot open"
+    assert video_io.open_reader(str(bad)) is None or video_io.open_reader(str(bad))[0].n == 0
+
+
+def test_run_cleans_up_when_analysis_fails(tmp_path, monkeypatch):
+    """An exception inside run()'s loop (a crowded frame -> TRL_ERR_CAPACITY, an allocation failure, ...) must not leave the
+    writer thread blocked on its queue or the files open: the long-lived service would leak both per failed request."""
+    import threading
+    from truely_amd import engine as eng_mod, model
+
+    class Boom(RuntimeError):
+        pass
+
+    class FakeEngine:
+        def detect_embed(self, frames):
+            raise Boom("libtruely_hip status -4: candidate list overflow")
+
+    fr = np.random.default_rng(2).integers(0, 255, (40, 24, 32, 3), dtype=np.uint8)
+    src, dst = str(tmp_path / "in.trlv"), str(tmp_path / "out.trlv")
+    video_io.write_raw(src, fr, 7.0)                                    # fps 7 -> every frame sampled
+    released = []
+    real_open = video_io.open_reader
+
+    def spy_open(path):
+        r = real_open(path)
+        rel = r[0].release
+        r[0].release = lambda: (released.append(path), rel())
+        return r
+
+    monkeypatch.setattr(video_io, "open_reader", spy_open)
+    monkeypatch.setattr(eng_mod, "_default", FakeEngine())
+    before = {t.ident for t in threading.enumerate()}
+    with pytest.raises(Boom):
+        model.run(src, dst)
+    assert released == [src]                                            # the reader was closed
+    left = [t for t in threading.enumerate() if t.ident not in before and t.name == "truely-writer" and t.is_alive()]
+    assert not left, "the writer thread survived the failed request"
+    rd, _f, _w, _h = real_open(dst)                                     # the sink was closed properly (header patched)
+    assert rd.n >= 0
+    rd.release()
+
+
+def test_analysis_service_spreads_requests_over_gpus():
+    """f3 widened: AnalysisService(gpus=[...]) keeps one worker (and engine) per GPU and hands each request to the least-loaded
+    one; a GPU's requests stay in arrival order; failures free their slot."""
+    import asyncio
+    import threading
+    import time
+    from truely_amd.service import AnalysisService
+    seen, lock = [], threading.Lock()
+    gate = threading.Event()
+
+    def fake_run(a, b, device=None):
+        if a.startswith("slow"):
+            gate.wait(5)
+        with lock:
+            seen.append((a, device))
+        if a == "boom":
+            raise RuntimeError("bad clip")
+        return 10 * device + len(a)
+
+    svc = AnalysisService(run_fn=fake_run, gpus=[0, 1, 2])
+    f1 = svc.submit("slow1", "o")                                       # GPU 0 (all idle: lowest ordinal)
+    f2 = svc.submit("slow22", "o")                                      # GPU 1
+    time.sleep(0.05)
+    assert [l for _g, l, _c in svc.loads()] == [1, 1, 0]
+    q0 = svc.submit("q0", "o")                                          # the idle GPU 2
+    assert q0.result(5) == 22                                           # ... finished while 0 and 1 are still busy
+    q1 = svc.submit("q1", "o")                                          # GPU 2 again: the only idle one
+    assert q1.result(5) == 22
+    q2, q3 = svc.submit("q2", "o"), svc.submit("q3", "o")               # q2 -> GPU 2 (load 0); q3 -> GPU 2 if q2 is done, else GPU 0
+    quick = [q0, q1, q2, q3]
+    assert q2.result(5) == 22
+    gate.set()
+    assert f1.result(5) == 5 and f2.result(5) == 16 and q3.result(5) in (2, 22)
+    with pytest.raises(RuntimeError):
+        svc.submit("boom", "o").result(5)
+    assert [l for _g, l, _c in svc.loads()] == [0, 0, 0] and (svc.completed, svc.failed) == (6, 1)
+
+    async def main():
+        return await asyncio.gather(*[svc.analyze(f"r{i}", "o") for i in range(6)])
+
+    res = asyncio.run(main())
+    svc.close()
+    assert sorted(r // 10 for r in res) == [0, 0, 1, 1, 2, 2]            # two each: the six requests were spread evenly
+    order0 = [a for a, d in seen if d == 0 and a.startswith("r")]
+    assert order0 == sorted(order0)                                     # arrival order within a GPU
+    with pytest.raises(ValueError):
+        AnalysisService(run_fn=fake_run, gpus=[])

@@ -308,18 +308,24 @@ __global__ __launch_bounds__(256) void k_nms_frame(int L, int cap, int capF, int
 // exclusive scan of per-frame counts; off[n] = total.  Also the candidate -> (frame, local) map.
 __global__ __launch_bounds__(256) void k_scan_counts(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off, int cap_total,
                                                      int32_t* __restrict__ flags, int slot) {
-    extern __shared__ int sh[];
-    for (int i = threadIdx.x; i < n; i += blockDim.x) sh[i] = cnt[i];
+    // thread t owns the contiguous run [t per, (t+1) per) of frames: fixed LDS whatever n is (any batch check_call admits)
+    __shared__ int part[257];
+    const int t = threadIdx.x, per = (n + 255) / 256;
+    const int b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
+    int s = 0;
+    for (int i = b; i < e; i++) s += cnt[i];
+    part[t] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (t == 0) {
         int run = 0;
-        for (int i = 0; i < n; i++) { const int v = sh[i]; sh[i] = run; run += v; }
-        sh[n] = run;
+        for (int i = 0; i < 256; i++) { const int v = part[i]; part[i] = run; run += v; }
+        part[256] = run;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i <= n; i += blockDim.x) off[i] = sh[i];
+    int run = part[t];
+    for (int i = b; i < e; i++) { off[i] = run; run += cnt[i]; }
     // the batch the next stage processes was sized by an optimistic capacity: report the real total and whether it fits
-    if (threadIdx.x == 0) { flags[4 + slot] = sh[n]; if (sh[n] > cap_total) flags[2 + slot] = 1; }
+    if (t == 0) { const int total = part[256]; off[n] = total; flags[4 + slot] = total; if (total > cap_total) flags[2 + slot] = 1; }
 }
 // Candidate list of a stage in launch order: candidate t = off[f] + i is box i of frame f.  The record holds what the front kernel
 // needs to start its crop -- frame index and pad()'s clamped window (detect_face.py pad(): x = max(x1, 1), ex = min(x2, W), crop
@@ -773,8 +779,10 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         c->cap_t2 = (int)(c2 < lim ? c2 : lim);
         c->cap_t3 = (int)(c3 < lim ? c3 : lim);
         const int ch2 = c->cap_t2 < TRL_CH2 ? c->cap_t2 : TRL_CH2, ch3 = c->cap_t3 < TRL_CH3 ? c->cap_t3 : TRL_CH3;
-        size_t need_x = (size_t)c->cap_t2 * 24 + (size_t)ch2 * (24 * 24 * 3 * 4 + 100 * 1024) + (1u << 20);
-        const size_t need3 = (size_t)c->cap_t3 * 64 + (size_t)ch3 * (48 * 48 * 3 * 4 + 640 * 1024) + (1u << 20);
+        // per candidate: the front kernel's pooled map + every activation of the tail (trl_run_rnet_tail / trl_run_onet_tail:
+        // R-Net 3388 + 3888 + 768 + 576 + 128 floats = 35 KB; O-Net 16928 + 28224 + 6400 + 4096 + 1024 + 1152 + 256 = 227 KB)
+        size_t need_x = (size_t)c->cap_t2 * 24 + (size_t)ch2 * (40 * 1024) + (1u << 20);
+        const size_t need3 = (size_t)c->cap_t3 * 64 + (size_t)ch3 * (240 * 1024) + (1u << 20);
         if (need3 > need_x) need_x = need3;
         if (c->cfg.pnet_mode == 0) { const size_t p = trl_pnet_fused_bytes(c, n, H, W) + (1u << 20); if (p > need_x) need_x = p; }
         if (c->scratch_after_cascade > need_x) need_x = c->scratch_after_cascade;   // the embedder that follows in the same call
@@ -828,7 +836,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     // (c->cap_t2, from earlier calls) and workgroups past the real total exit at once; if the total exceeds the capacity a
     // flag is raised and the caller re-runs the call with a larger one (trl_cascade_run).
     const int cap2 = c->cap_t2, cap3 = c->cap_t3;
-    k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n1, n, B.off2, cap2, B.flags, 0);
+    k_scan_counts<<<1, 256, 0, s>>>(B.n1, n, B.off2, cap2, B.flags, 0);
     TRL_LAUNCH_CHECK();
     k_build_map<<<n, 64, 0, s>>>(B.n1, B.off2, B.s1_box, capF, W, H, B.cbox);
     TRL_LAUNCH_CHECK();
@@ -850,7 +858,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     TRL_LAUNCH_CHECK();
 
     // ---- stage 3: ONet --------------------------------------------------------------------------------
-    k_scan_counts<<<1, 256, (n + 1) * sizeof(int), s>>>(B.n2, n, B.off3, cap3, B.flags, 1);
+    k_scan_counts<<<1, 256, 0, s>>>(B.n2, n, B.off3, cap3, B.flags, 1);
     TRL_LAUNCH_CHECK();
     k_build_map<<<n, 64, 0, s>>>(B.n2, B.off3, B.s2_box, capF, W, H, B.cbox);
     TRL_LAUNCH_CHECK();
@@ -902,8 +910,11 @@ int trl_cascade_check(trl_ctx* c, int n, int* retry) {
     if (f[2]) { c->t2_per_frame = want2; *retry = 1; }       // stage 3 ran on an incomplete stage 2: its total is meaningless
     else if (f[3]) { c->t3_per_frame = want3; *retry = 1; }
     if (!*retry) {
-        if (want2 > c->t2_per_frame) c->t2_per_frame = want2;
-        if (want3 > c->t3_per_frame) c->t3_per_frame = want3;
+        // follow the content: grow at once, decay 3 % per call towards what recent batches needed (never below the start values),
+        // so one crowded batch does not inflate every later call's launches and workspace for the life of the context
+        const float d2 = 0.97f * c->t2_per_frame, d3 = 0.97f * c->t3_per_frame;
+        c->t2_per_frame = want2 > d2 ? want2 : (d2 > 160.f ? d2 : (c->t2_per_frame < 160.f ? c->t2_per_frame : 160.f));
+        c->t3_per_frame = want3 > d3 ? want3 : (d3 > 48.f ? d3 : (c->t3_per_frame < 48.f ? c->t3_per_frame : 48.f));
     }
     return TRL_OK;
 }

@@ -52,7 +52,7 @@ def analyze_video(frames, fps: int = 30, frame_count: int | None = None, engine:
     return out
 
 
-def run(video_path_one: str, video_path_two: str) -> int:
+def run(video_path_one: str, video_path_two: str, engine: Engine | None = None) -> int:
     """server/model.py::run, streaming: memory is bounded by ONE batch of decoded frames (BATCH sampled frames and the
     frames between them), not by the clip -- a 10-minute 720p clip held in a Python list, as a literal port would, is ~50 GB.
 
@@ -62,6 +62,9 @@ def run(video_path_one: str, video_path_two: str) -> int:
     encoding on their own thread).  Clips whose container yields NV12 (a hardware decoder's output) take the device ingest
     path: the whole window is copied to the GPU through pinned memory as NV12 (1.5 B/pixel), converted to BGR there
     (``trl_ingest_nv12``), the sampled frames are analysed in place and the BGR frames come back for the writer.
+
+    ``engine`` (optional, not in the reference's signature): the context to run on -- a multi-GPU service keeps one per device
+    (service.AnalysisService(gpus=[...])); default: the process-wide engine on the current device.
 
     Environment: TRUELY_ANNOTATE=0 writes the frames without boxes / text; TRUELY_WRITE_OUTPUT=0 skips the output stage
     (benchmarking only: the server requires a non-empty file, server.py:612-627)."""
@@ -80,10 +83,10 @@ def run(video_path_one: str, video_path_two: str) -> int:
         print(f"Error: Invalid video properties: width={width}, height={height}, fps={fps}")
         cap.release()
         return 0
-    eng = default_engine()
+    eng = engine or default_engine()
     nv12 = getattr(cap, "pixfmt", "bgr") == "nv12"
     write_out = os.environ.get("TRUELY_WRITE_OUTPUT", "1") != "0"
-    sink = video_io.open_writer(video_path_two, fps, (width, height), isinstance(cap, (video_io.RawReader, video_io.Y4MReader))) if write_out else None
+    sink = video_io.open_writer(video_path_two, fps, (width, height)) if write_out else None
     writer = video_io.AsyncWriter(sink, annotate=os.environ.get("TRUELY_ANNOTATE", "1") != "0")
     step = max(1, int(fps / 7))   # model.py:40
     frame_count = 0
@@ -101,8 +104,12 @@ def run(video_path_one: str, video_path_two: str) -> int:
             from .ingest import Nv12Uploader
             if uploader is None:
                 uploader = Nv12Uploader(eng, height, width, BATCH * step)
-            bgr_dev = uploader.upload(np.stack(window), 1)  # every frame of the window, converted on the device
-            sampled = bgr_dev[off::step].contiguous()
+            if write_out:                                   # every frame of the window is converted: the writer needs them all
+                bgr_dev = uploader.upload(np.stack(window), 1)
+                sampled = bgr_dev[off::step].contiguous()
+            else:                                           # only the sampled frames travel to the GPU at all
+                bgr_dev = None
+                sampled = uploader.upload(np.stack(window[off::step]), 1) if len(window) > off else None
         else:
             bgr_dev = None
             sampled = np.stack(window[off::step]) if len(window) > off else None
@@ -125,16 +132,27 @@ def run(video_path_one: str, video_path_two: str) -> int:
         first += len(window)
         window = []
 
-    while cap.isOpened():
-        ret, frame = cap.read()
-        if not ret:
-            break
-        window.append(frame)
-        frame_count += 1
-        if len(window) == BATCH * step:
-            flush()
-    flush()
-    cap.release()
+    # Whatever fails in the loop -- TRL_ERR_CAPACITY from a crowded frame, an allocation failure, a damaged clip -- the writer
+    # thread must end and both files must be closed: a long-lived service (service.AnalysisService) would otherwise leak one
+    # blocked thread and two file handles per failed request.
+    try:
+        while cap.isOpened():
+            ret, frame = cap.read()
+            if not ret:
+                break
+            window.append(frame)
+            frame_count += 1
+            if len(window) == BATCH * step:
+                flush()
+        flush()
+    except BaseException:
+        try:
+            writer.close()                   # its own error, if any, must not mask the one in flight
+        except Exception:  # noqa: BLE001
+            pass
+        raise
+    finally:
+        cap.release()
     writer.close()
     if frame_count == 0:    # model.py:83-85
         print("Error: No frames were processed")

@@ -9,6 +9,7 @@ clip is (the server logs it) and `samples()` hands the coded access units to wha
 decoder yields NV12, which `model.run` ingests on the device)."""
 from __future__ import annotations
 
+import mmap
 import struct
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
@@ -33,6 +34,25 @@ class Mp4Info:
     @property
     def fps(self) -> float:
         return self.frame_count * self.timescale / self.duration if self.duration else 0.0
+
+
+MAX_SAMPLES = 10_000_000       # ~92 hours at 30 fps: anything above is a damaged or hostile container
+
+
+class Mp4Error(ValueError):
+    """The container declares something its bytes cannot hold (counts past the end of a box, absurd sample numbers)."""
+
+
+def _count(buf, off: int, box_end: int, entry_bytes: int, what: str, first_entry: int | None = None) -> int:
+    """A 32-bit entry count read from a box, checked against what the box can hold BEFORE anything is allocated or looped over:
+    the count fields of stsz / stco / stsc / trun come straight from an upload."""
+    if off + 4 > box_end:
+        raise Mp4Error(f"{what}: truncated box")
+    (n,) = struct.unpack_from(">I", buf, off)
+    start = off + 4 if first_entry is None else first_entry
+    if n > MAX_SAMPLES or (entry_bytes and n * entry_bytes > max(0, box_end - start)):
+        raise Mp4Error(f"{what}: {n} entries do not fit the box")
+    return n
 
 
 def _boxes(buf: bytes, off: int, end: int):
@@ -60,7 +80,17 @@ def _find(buf, off, end, *path):
 def probe(path: str) -> Optional[Mp4Info]:
     """Parse the container; None if the file is not an ISO-BMFF file with an H.264 video track."""
     with open(path, "rb") as f:
-        buf = f.read()
+        try:
+            buf = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)      # never the whole upload in memory
+        except ValueError:                                                # empty file
+            return None
+    try:
+        return _probe(buf)
+    finally:
+        buf.close()
+
+
+def _probe(buf) -> Optional[Mp4Info]:
     if len(buf) < 16 or buf[4:8] != b"ftyp":
         return None
     moov = _find(buf, 0, len(buf), b"moov")
@@ -108,26 +138,40 @@ def probe(path: str) -> Optional[Mp4Info]:
         return None
     # ---- plain file: sample tables ---------------------------------------------------------------------------------
     stsz = _find(buf, *stbl, b"stsz")
-    uniform, count = struct.unpack_from(">II", buf, stsz[0] + 4)
+    if stsz is None:
+        raise Mp4Error("no stsz box")
+    (uniform,) = struct.unpack_from(">I", buf, stsz[0] + 4)
+    # a uniform sample size needs no table: the count is then bounded by the file (every sample occupies >= 1 byte of it)
+    count = _count(buf, stsz[0] + 8, stsz[1], 0 if uniform else 4, "stsz")
+    if uniform and count * max(1, uniform) > len(buf):
+        raise Mp4Error(f"stsz: {count} samples of {uniform} bytes exceed the file")
     if count:
-        sizes = [uniform] * count if uniform else list(struct.unpack_from(f">{count}I", buf, stsz[0] + 12))
+        sizes = None if uniform else struct.unpack_from(f">{count}I", buf, stsz[0] + 12)
         co = _find(buf, *stbl, b"stco")
         if co is not None:
-            (n,) = struct.unpack_from(">I", buf, co[0] + 4); chunks = list(struct.unpack_from(f">{n}I", buf, co[0] + 8))
+            n = _count(buf, co[0] + 4, co[1], 4, "stco"); chunks = struct.unpack_from(f">{n}I", buf, co[0] + 8)
         else:
             co = _find(buf, *stbl, b"co64")
-            (n,) = struct.unpack_from(">I", buf, co[0] + 4); chunks = list(struct.unpack_from(f">{n}Q", buf, co[0] + 8))
+            if co is None:
+                raise Mp4Error("no chunk offset box")
+            n = _count(buf, co[0] + 4, co[1], 8, "co64"); chunks = struct.unpack_from(f">{n}Q", buf, co[0] + 8)
         sc = _find(buf, *stbl, b"stsc")
-        (n,) = struct.unpack_from(">I", buf, sc[0] + 4)
+        if sc is None:
+            raise Mp4Error("no stsc box")
+        n = _count(buf, sc[0] + 4, sc[1], 12, "stsc")
         runs = [struct.unpack_from(">III", buf, sc[0] + 8 + 12 * i) for i in range(n)]
-        s = 0
+        if not runs or runs[0][0] != 1:
+            raise Mp4Error("stsc: no run for the first chunk")
+        s, ri = 0, 0
         for ci, base in enumerate(chunks):
-            per = [r[1] for r in runs if r[0] <= ci + 1][-1]
+            while ri + 1 < len(runs) and runs[ri + 1][0] <= ci + 1:      # runs are sorted by first_chunk: one forward cursor
+                ri += 1
             off = base
-            for _ in range(per):
-                if s >= count:
-                    break
-                info.sample_ranges.append((off, sizes[s])); off += sizes[s]; s += 1
+            for _ in range(min(runs[ri][1], count - s)):
+                sz = uniform if sizes is None else sizes[s]
+                info.sample_ranges.append((off, sz)); off += sz; s += 1
+            if s >= count:
+                break
         info.frame_count = count
         return info
     # ---- fragmented file: moof / traf / trun -------------------------------------------------------------------------
@@ -155,7 +199,15 @@ def probe(path: str) -> Optional[Mp4Info]:
                 if t3 != b"trun":
                     continue
                 fl = struct.unpack_from(">I", buf, a3)[0] & 0xFFFFFF
-                (n,) = struct.unpack_from(">I", buf, a3 + 4)
+                per = 4 * (bool(fl & 0x100) + bool(fl & 0x200) + bool(fl & 0x400) + bool(fl & 0x800))
+                q = a3 + 8 + 4 * (bool(fl & 0x1) + bool(fl & 0x4))
+                n = _count(buf, a3 + 4, b3, per, "trun", first_entry=q)
+                if not (fl & 0x200) and dsz == 0 and n:
+                    raise Mp4Error("trun: samples with neither a per-sample nor a default size")
+                if per == 0 and n * max(1, dsz) > len(buf):
+                    raise Mp4Error(f"trun: {n} samples of {dsz} bytes exceed the file")
+                if info.frame_count + n > MAX_SAMPLES:
+                    raise Mp4Error("trun: too many samples")
                 q = a3 + 8
                 off = base
                 if fl & 0x1: off = base + struct.unpack_from(">i", buf, q)[0]; q += 4

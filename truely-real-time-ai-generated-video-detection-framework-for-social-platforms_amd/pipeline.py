@@ -111,8 +111,9 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
     def slot_views(i, n):
         if ring["faces"] is None:
             ring["n"] = n
-            ring["faces"] = torch.empty((R, n, S, S, 3), dtype=torch.float32, device=dev)
-            ring["valid"] = torch.empty((R, n), dtype=torch.uint8, device=dev)
+            with torch.cuda.stream(torch.cuda.default_stream(dev)):     # shared by every stream of the run: not owned by one of them
+                ring["faces"] = torch.empty((R, n, S, S, 3), dtype=torch.float32, device=dev)
+                ring["valid"] = torch.empty((R, n), dtype=torch.uint8, device=dev)
         if n > ring["n"]:
             raise ValueError("batches must not grow after the first one")
         k = i % R
@@ -185,9 +186,9 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
             finish(j)
             collect()
         retire(block_for=i)
-        b = get(i, j)
-        fv, vv = slot_views(i, int(b.shape[0]))
-        with torch.cuda.stream(streams[j]):
+        with torch.cuda.stream(streams[j]):              # (the batch source may queue work of its own: NV12 conversion)
+            b = get(i, j)
+            fv, vv = slot_views(i, int(b.shape[0]))
             engines[j].detect_embed_begin(b, crop=True, faces=fv, valid=vv)
         inflight[j] = i
     for k in range(K, K + F):

@@ -7,6 +7,8 @@ the build environment, so two back-ends exist behind the same tiny interface:
 * ``cv2`` when importable (real .mp4 in, annotated .mp4 out, like the reference);
 * the raw "TRLV" container (fps header + uint8 frames, BGR or -- what a hardware decoder hands over -- NV12) used by the
   tests and the benchmark.  NV12 clips take the device ingest path of ``model.run`` (SURVEY section 8(f) rank 1);
+* Motion-JPEG in AVI (``AviMjpegWriter`` / ``AviMjpegReader``, Pillow's libjpeg): the annotated OUTPUT when OpenCV is absent -- a
+  bounded standard file instead of raw frames -- and the one compressed INPUT this build decodes by itself;
 * YUV4MPEG2 (``.y4m``, 4:2:0 progressive): the uncompressed interchange format every decoder can emit
   (``ffmpeg -i clip.mp4 -pix_fmt yuv420p clip.y4m``).  Planes are repacked to NV12 on the fly and take the same device ingest.
 ``AsyncWriter`` is the decoupled, skippable annotated-output stage: drawing and encoding run on their
@@ -160,6 +162,173 @@ def write_raw(path, frames: np.ndarray, fps: float, pixfmt: str = "bgr", size=No
     w.release()
 
 
+class AviMjpegWriter:
+    """Motion-JPEG in an AVI 1.0 container (RIFF 'AVI ': hdrl / movi with '00dc' chunks / idx1), frames encoded with Pillow's
+    libjpeg on the writer thread.  The output stage of ``run()`` when OpenCV is absent: a bounded, standard file any player opens
+    (a 10-minute 720p clip is ~1.5 GB instead of the ~50 GB of raw frames).  The reference writes H.264 through
+    ``cv2.VideoWriter`` (server/model.py:35-36,77); H.264 needs OpenCV -- see INTEGRATION.md.  AVI 1.0 sizes are 32-bit: frames
+    past ~3.9 GB are dropped with a warning and the file is still closed properly."""
+    LIMIT = 0xE8000000
+
+    def __init__(self, path, fps, size, quality: int = 80, threads: int | None = None):
+        from PIL import Image                        # noqa: F401  (fail at open time, not on the writer thread)
+        import collections
+        import concurrent.futures
+        self.path, self.w, self.h, self.fps, self.quality = path, int(size[0]), int(size[1]), max(1, int(round(fps))), int(quality)
+        self.threads = int(os.environ.get("TRUELY_ENCODE_THREADS", "1")) if threads is None else int(threads)
+        self.pool = concurrent.futures.ThreadPoolExecutor(self.threads, thread_name_prefix="truely-jpeg") if self.threads > 1 else None
+        self.inflight = collections.deque()
+        self.f = open(path, "wb")
+        self.index: list = []                        # (offset relative to 'movi', size)
+        self.n = self.dropped = 0
+        self.max_chunk = 0
+        self.f.write(self._header(0, 0, 0))
+        self.movi_start = self.f.tell() - 4          # position of the 'movi' fourcc
+        self.pos = 4                                 # bytes of the movi list written so far ('movi' itself)
+
+    def _header(self, nframes, movi_bytes, max_chunk):
+        w, h, fps = self.w, self.h, self.fps
+        avih = struct.pack("<IIIIIIIIII4I", 1000000 // fps, max_chunk * fps, 0, 0x10, nframes, 0, 1, max_chunk, w, h, 0, 0, 0, 0)
+        strh = struct.pack("<4s4sIHHIIIIIIIIhhhh", b"vids", b"MJPG", 0, 0, 0, 0, 1, fps, 0, nframes, max_chunk, 0xFFFFFFFF, 0, 0, 0, w, h)
+        strf = struct.pack("<IiiHH4sIiiII", 40, w, h, 1, 24, b"MJPG", w * h * 3, 0, 0, 0, 0)
+        strl = b"strl" + b"strh" + struct.pack("<I", len(strh)) + strh + b"strf" + struct.pack("<I", len(strf)) + strf
+        hdrl = b"hdrl" + b"avih" + struct.pack("<I", len(avih)) + avih + b"LIST" + struct.pack("<I", len(strl)) + strl
+        head = b"LIST" + struct.pack("<I", len(hdrl)) + hdrl
+        idx_bytes = 8 + 16 * nframes
+        riff_size = 4 + len(head) + 8 + movi_bytes + idx_bytes
+        return b"RIFF" + struct.pack("<I", riff_size & 0xFFFFFFFF) + b"AVI " + head + b"LIST" + struct.pack("<I", movi_bytes) + b"movi"
+
+    def _encode(self, frame) -> bytes:
+        from PIL import Image
+        import io
+        a = np.ascontiguousarray(np.asarray(frame, np.uint8)[:, :, ::-1])      # BGR (cap.read()) -> RGB
+        buf = io.BytesIO()
+        Image.fromarray(a, "RGB").save(buf, format="JPEG", quality=self.quality, subsampling=2)
+        return buf.getvalue()
+
+    def _append(self, data: bytes):
+        if self.pos > self.LIMIT:
+            if not self.dropped:
+                print(f"Warning: {self.path} reached the 4 GB AVI limit; further frames are not written")
+            self.dropped += 1
+            return
+        pad = len(data) & 1
+        self.f.write(b"00dc" + struct.pack("<I", len(data)) + data + (b"\0" if pad else b""))
+        self.index.append((self.pos, len(data)))
+        self.pos += 8 + len(data) + pad
+        self.max_chunk = max(self.max_chunk, len(data))
+        self.n += 1
+
+    def write(self, frame):
+        """Encode + append.  TRUELY_ENCODE_THREADS > 1 encodes on a small pool and appends in call order (at most 2 x threads
+        encoded frames wait in memory); measured here Pillow's encoder holds the GIL for most of a frame (x1.3 with four
+        threads, ~750 frames/s of 360p per core), so the default is the writer thread alone."""
+        if self.pool is None:
+            self._append(self._encode(frame))
+            return
+        self.inflight.append(self.pool.submit(self._encode, np.array(frame, np.uint8, copy=True)))
+        while len(self.inflight) > 2 * self.threads:
+            self._append(self.inflight.popleft().result())
+
+    def release(self):
+        while self.inflight:
+            self._append(self.inflight.popleft().result())
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+        idx = b"".join(b"00dc" + struct.pack("<III", 0x10, off, size) for off, size in self.index)
+        self.f.write(b"idx1" + struct.pack("<I", len(idx)) + idx)
+        self.f.seek(0)
+        self.f.write(self._header(self.n, self.pos, self.max_chunk))
+        self.f.close()
+
+
+class AviMjpegReader:
+    """Reads the Motion-JPEG AVI files ``AviMjpegWriter`` (or any encoder: ``ffmpeg -c:v mjpeg out.avi``) produces: walks the
+    'movi' list, decodes each '00dc' / '00db' chunk with Pillow -> BGR frames like ``cap.read()``.  The one COMPRESSED input
+    this build can decode without OpenCV."""
+    pixfmt = "bgr"
+
+    def __init__(self, path):
+        self.f = open(path, "rb")
+        head = self.f.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"AVI ":
+            self.f.close()
+            raise ValueError("not an AVI file")
+        fsize = os.path.getsize(path)
+        self.width = self.height = 0
+        self.fps_f, self.n, self.codec = 0.0, 0, b""
+        self.frames: list = []                       # (file offset, size)
+        pos = 12
+        while pos + 8 <= fsize:
+            self.f.seek(pos)
+            cid, csz = struct.unpack("<4sI", self.f.read(8))
+            if cid == b"LIST":
+                ltype = self.f.read(4)
+                if ltype == b"hdrl":
+                    self._parse_hdrl(self.f.read(max(0, min(csz - 4, 1 << 20))))
+                elif ltype == b"movi":
+                    self._walk_movi(pos + 12, min(pos + 8 + csz, fsize))
+            pos += 8 + csz + (csz & 1)
+        if self.codec.upper() not in (b"MJPG", b"JPEG") or self.width <= 0 or self.height <= 0:
+            self.f.close()
+            raise ValueError(f"AVI video codec {self.codec!r}: only Motion-JPEG can be decoded without OpenCV")
+        self.n = len(self.frames)
+        self.i = 0
+
+    def _parse_hdrl(self, b):
+        p = 0
+        while p + 8 <= len(b):
+            cid, csz = struct.unpack_from("<4sI", b, p)
+            if cid == b"LIST":
+                p += 12
+                continue
+            body = b[p + 8:p + 8 + csz]
+            if cid == b"strh" and len(body) >= 32 and body[:4] == b"vids":
+                self.codec = body[4:8]
+                scale, rate = struct.unpack_from("<II", body, 20)
+                self.fps_f = rate / scale if scale else 0.0
+            elif cid == b"strf" and len(body) >= 20 and not self.width:
+                self.width, self.height = struct.unpack_from("<ii", body, 4)
+                self.height = abs(self.height)
+                if not self.codec.strip(b"\0"):
+                    self.codec = body[16:20]
+            p += 8 + csz + (csz & 1)
+
+    def _walk_movi(self, pos, end):
+        while pos + 8 <= end and len(self.frames) < 10_000_000:
+            self.f.seek(pos)
+            cid, csz = struct.unpack("<4sI", self.f.read(8))
+            if cid == b"LIST":                       # 'rec ' groups
+                pos += 12
+                continue
+            if cid[2:4] in (b"dc", b"db") and csz > 0 and pos + 8 + csz <= end:
+                self.frames.append((pos + 8, csz))
+            pos += 8 + csz + (csz & 1)
+
+    def isOpened(self):
+        return True
+
+    def read(self):
+        from PIL import Image
+        import io
+        if self.i >= self.n:
+            return False, None
+        off, size = self.frames[self.i]
+        self.f.seek(off)
+        try:
+            im = Image.open(io.BytesIO(self.f.read(size))).convert("RGB")
+        except Exception:  # noqa: BLE001 - a damaged frame ends the clip like a failed cap.read()
+            return False, None
+        self.i += 1
+        a = np.asarray(im, np.uint8)
+        if a.shape[0] != self.height or a.shape[1] != self.width:
+            return False, None
+        return True, np.ascontiguousarray(a[:, :, ::-1])
+
+    def release(self):
+        self.f.close()
+
+
 class AsyncWriter:
     """Decoupled annotated-output stage.  ``put(frame, note)`` hands a frame (and, for sampled frames that were compared with
     their predecessor, ``note = (frame_index, rect, flagged)``) to a worker thread that draws (annotate.py) and encodes.
@@ -218,6 +387,13 @@ def open_reader(path):
             print(f"Error: {e}")
             return None
         return r, int(r.fps_f), r.width, r.height
+    if magic[:4] == b"RIFF" and cv2 is None:
+        try:
+            r = AviMjpegReader(path)
+        except (ValueError, struct.error, OSError) as e:
+            print(f"Error: {e}")
+            return None
+        return r, int(r.fps_f), r.width, r.height
     if cv2 is not None:  # pragma: no cover
         cap = cv2.VideoCapture(path)
         if not cap.isOpened():
@@ -240,10 +416,15 @@ def describe(path) -> str:
             f"{' (fragmented mp4)' if i.fragmented else ''}: decoding needs opencv-python (cv2.VideoCapture), or hand run() decoder output as an NV12 TRLV clip")
 
 
-def open_writer(path, fps, size, like_raw: bool):
-    if cv2 is not None and not like_raw:  # pragma: no cover
+def open_writer(path, fps, size, like_raw: bool = False):
+    """The sink of ``run()``'s annotated output (server/model.py:35-36).  ``*.trlv``: the raw container (tests, byte-exact
+    read-back).  Otherwise OpenCV's H.264 writer when importable, like the reference; without OpenCV a Motion-JPEG AVI stream
+    (bounded size, plays anywhere -- but it is MJPEG/AVI whatever the file is called: H.264 needs OpenCV)."""
+    if str(path).lower().endswith(".trlv"):
+        return RawWriter(path, fps, size)
+    if cv2 is not None:  # pragma: no cover
         return cv2.VideoWriter(path, cv2.VideoWriter_fourcc(*"H264"), fps, size)
-    return RawWriter(path, fps, size)
+    return AviMjpegWriter(path, fps, size)
 
 
 def draw_box(frame: np.ndarray, x0, y0, x1, y1, color, thickness=2):
