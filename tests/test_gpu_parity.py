@@ -134,6 +134,35 @@ def test_fused_pnet_kernel_maps_bit_exact(blob, oracle, H, W, seed):
             assert np.array_equal(rows["box"][:, 0], q1x) and np.array_equal(rows["box"][:, 3], q2y)
 
 
+@pytest.mark.parametrize("run", [2, 5, 8])
+def test_pnet_halo_carry_is_bit_exact(blob, oracle, run):
+    """The fused PNet kernel hands a workgroup RUNS of consecutive tiles; a tile that follows its left neighbour takes the 4 pooled
+    and 2 conv2 halo columns the neighbour already computed out of LDS instead of recomputing them (conv1 80 instead of 100
+    M-tiles, conv2 18 instead of 21).  Large batches run with 8-tile runs; here the run length is forced on small frames: with
+    thr0 = 0 every cell of every level's probability / regression map is compared with the oracle, for run lengths that do and do
+    not divide the tile rows, then the whole cascade on frames whose levels are many tiles wide (interior + edge tiles)."""
+    from truely_amd.engine import Engine
+    eng0 = Engine(blob, thresholds=(0.0, 0.7, 0.7), cap_level=3072, cap_frame=3072)
+    eng0.pnet_run(run)
+    for (H, W, seed) in [(120, 160, 41), (97, 131, 21), (70, 237, 5)]:
+        fr = truely_amd.synthetic.synthetic_frames(2, H, W, seed=seed)
+        eng0.poison_workspaces(0xFF)
+        eng0.mtcnn_detect(fr)
+        for f in range(2):
+            for l, (sc, h, w) in enumerate(oracle.scales(H, W)):
+                p_ref, r_ref = oracle.pnet_level(oracle.area_resample_norm(fr[f], 0, H, 0, W, h, w))
+                rows = eng0.level_cands(f, l)
+                assert len(rows) == p_ref.size, (H, W, f, l)
+                assert np.array_equal(rows["score"], p_ref.reshape(-1)), f"{H}x{W} frame {f} level {l}: prob map"
+                assert np.array_equal(rows["reg"], r_ref.reshape(-1, 4)), f"{H}x{W} frame {f} level {l}: reg map"
+    eng = Engine(blob)
+    eng.pnet_run(run)
+    _check_cascade(eng, oracle, truely_amd.synthetic.synthetic_frames(3, 360, 640, seed=11))
+    _check_cascade(eng, oracle, truely_amd.synthetic.synthetic_frames(2, 211, 333, seed=12))
+    if run == 8:
+        _check_cascade(eng, oracle, truely_amd.synthetic.synthetic_frames(2, 720, 1280, seed=0))
+
+
 def test_landmarks_export(engine, oracle):
     """`mtcnn.detect(frame, landmarks=True)`: O-Net's five points, ordered like the boxes (largest area first)."""
     from truely_amd.mtcnn import MTCNN
@@ -298,9 +327,12 @@ def test_cascade_fused_pnet_prelu_variants(variant):
     blob = _slope_variant_blob(variant)
     eng, orc = Engine(blob), Oracle(blob)
     _check_cascade(eng, orc, frames_small(4, 180, 320))
+    eng.pnet_run(4)                                              # ... and through the halo-carry path of the same instantiation
+    _check_cascade(eng, orc, frames_small(4, 180, 320))
     _check_cascade(eng, orc, truely_amd.synthetic.synthetic_frames(2, 97, 131, seed=21))
     # the fused kernel's own maps, interior and edge tiles, sub-threshold cells included
     eng0 = Engine(blob, thresholds=(0.0, 0.7, 0.7), cap_level=3072, cap_frame=3072)
+    eng0.pnet_run(3)
     H, W = 97, 131
     fr = truely_amd.synthetic.synthetic_frames(1, H, W, seed=23)
     eng0.poison_workspaces(0xFF)

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "trl_debug_crop_aligned": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "trl_debug_timings": (C.c_int, [_vp, C.POINTER(_f)]),
     "trl_debug_stage_totals": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "trl_debug_pnet_run": (C.c_int, [_vp, _i]),
     "trl_debug_pnet_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -667,6 +667,14 @@ int trl_debug_stage_totals(trl_ctx* c, int32_t* h_out2) {
     return TRL_OK;
 }
 
+// test / tuning hook: consecutive tiles a workgroup of the fused PNet launch takes per cursor fetch (0 = automatic).  Runs > 1
+// let a tile reuse its left neighbour's halo columns (the carry path); results are identical for every value.
+int trl_debug_pnet_run(trl_ctx* c, int run) {
+    if (!c || run < 0 || run > 64) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    c->pnet_run = run;
+    return TRL_OK;
+}
+
 int trl_debug_pnet_kernel_ms(trl_ctx* c, float* ms) {
     if (!c || !ms) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
     *ms = c->pnet_kernel_ms;

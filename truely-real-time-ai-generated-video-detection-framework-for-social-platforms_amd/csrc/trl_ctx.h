@@ -49,6 +49,7 @@ struct trl_ctx {
     float last_ms[4] = {0, 0, 0, 0};
     int pnet_mono1 = 0;              // conv1 PReLU slopes all >= 0
     int pnet_unit = 0;               // no PNet PReLU slope above 1 (negative ones allowed): prelu(v) == max(v, s v)
+    int pnet_run = 0;                // > 0: tiles per cursor fetch of the fused PNet launch (trl_debug_pnet_run); 0 = automatic
     int32_t* pnet_cursor = nullptr;           // device: 8 per-XCD tile cursors of the fused PNet launch
     unsigned long long* pnet_clk = nullptr;   // device: first-start / last-end wall clock of the fused PNet launch
     float pnet_kernel_ms = 0.f;      // its span in ms (collect_timings)

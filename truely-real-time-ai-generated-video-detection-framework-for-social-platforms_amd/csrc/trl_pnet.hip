@@ -46,6 +46,14 @@ constexpr int REGION_A = C2_T * C2_T * C2_LD;        // 5508 floats: input tile,
 constexpr int REGION_B = 4 * 32 * ST_LD;             // 4224 floats: pooled conv1, later conv3 staging
 static_assert(3 * 7 * 256 <= REGION_A, "input tile (+ the 28 overhang pixels of the 7x256 copy) fits region A");
 static_assert(P1_T * P1_T * 10 <= REGION_B, "pooled tile fits region B");
+// Horizontal carry between consecutive tiles of a tile row (a workgroup takes RUNS of consecutive tiles): the right-most 4 pooled
+// columns and 2 conv2 columns of tile (ty, tx) ARE the left-most ones of tile (ty, tx + 1) -- the halo that 16x16-cell tiles
+// otherwise compute twice (conv1 x1.56, conv2 x1.27 of the useful work).  They are kept in LDS across the tile boundary, and a tile
+// that follows its left neighbour computes only 16 new pooled columns (80 instead of 100 conv1 M-tiles) and 16 new conv2 columns
+// (18 instead of 21 M-tiles).  Same values: every cell is the same fmaf chain over the same pixels whichever tile computes it.
+constexpr int CARRY_P = P1_T * 4 * 10;               // 800 floats: pooled rows x 4 columns x 10 channels
+constexpr int CARRY_C = C2_T * 2 * C2_LD;            // 612 floats: conv2 rows x 2 columns x 17 (padded channels)
+constexpr int DYN_LDS = (144 * 32 + CARRY_P + CARRY_C) * 4;   // conv3 weights + the two carry strips (dynamic: static LDS is capped at 64 KB)
 
 // One pyramid pixel = three floats (a fourth padding float would be 25 % of the pyramid's write + read traffic).
 struct PyrPx { float b, g, r; };
@@ -81,6 +89,7 @@ struct PnetArgs {
     int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); read by the DBG instantiation only
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
     int32_t* xcd_next;                         // per-XCD dynamic tile cursor (8 counters, zeroed before the launch)
+    int run;                                   // consecutive tiles a workgroup takes per cursor fetch (>= 1)
     unsigned long long* clk;                   // [0] = earliest workgroup start, [1] = latest workgroup end (device wall clock)
 };
 
@@ -394,7 +403,10 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
     __shared__ float HSall[4 * 32 * 9];                           // per-wave head outputs [32 cells][9]
-    __shared__ __attribute__((aligned(16))) float B3S[144 * 32]; // conv3 weights [k][cout]: read per k-chain batch, not held in VGPRs
+    extern __shared__ __attribute__((aligned(16))) float DYN[];  // DYN_LDS bytes, then whatever a tuning run pads (TRL_PNET_XLDS)
+    float* const B3S = DYN;                                       // conv3 weights [k][cout]: read per k-chain batch, not held in VGPRs
+    float* const CP = DYN + 144 * 32;                             // carried pooled columns [20][4][10]
+    float* const CC = CP + CARRY_P;                               // carried conv2 columns  [18][2][17]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every M-tile index below is SALU work
@@ -499,23 +511,62 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         }
     };
     float* const HS = HSall + wave * 32 * 9;
-    // Dynamic schedule inside the XCD's chunk: a workgroup takes the next tile of its XCD from an atomic cursor, so one that
-    // starts late (another stream's kernel still on its CU) or loses time simply processes fewer tiles; the cursor value for
-    // tile i+1 is fetched at the top of tile i and travels through LDS (the loop's own barriers order it).
+    // Carry strips <-> tiles, a handful of instructions per tile (VALU beside the MFMAs is paid in matrix throughput): the pooled
+    // strip is 20 rows x 40 floats = 10 float4 per row (16 threads per row, 10 active: rows 0..15 in one pass, 16..19 in a second);
+    // the conv2 strip is 18 rows x 34 floats = 17 float2 per row (32 threads per row, 17 active: three passes).
+    typedef float f32x2c __attribute__((ext_vector_type(2)));
+    auto copy_pooled = [&](auto SAVE_T) {
+        constexpr bool SAVE = decltype(SAVE_T)::value;          // tile -> strip (columns 16..19), or strip -> tile (columns 0..3)
+        const int q = tid & 15;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int r = (tid >> 4) + 16 * pass;
+            if (q < 10 && (pass == 0 || tid < 64)) {
+                f32x4* t = reinterpret_cast<f32x4*>(RB + r * (P1_T * 10) + (SAVE ? 16 * 10 : 0) + 4 * q);
+                f32x4* c = reinterpret_cast<f32x4*>(CP + r * 40 + 4 * q);
+                if (SAVE) *c = *t; else *t = *c;
+            }
+        }
+    };
+    auto copy_conv2 = [&](auto SAVE_T) {
+        constexpr bool SAVE = decltype(SAVE_T)::value;          // columns 16..17 -> strip, or strip -> columns 0..1
+        const int q = tid & 31;
+#pragma unroll
+        for (int pass = 0; pass < 3; pass++) {
+            const int r = (tid >> 5) + 8 * pass;
+            if (q < 17 && (pass < 2 || tid < 64)) {
+                f32x2c* t = reinterpret_cast<f32x2c*>(RA + r * (C2_T * C2_LD) + (SAVE ? 16 * C2_LD : 0) + 2 * q);
+                f32x2c* c = reinterpret_cast<f32x2c*>(CC + r * 34 + 2 * q);
+                if (SAVE) *c = *t; else *t = *c;
+            }
+        }
+    };
+    // Dynamic schedule inside the XCD's chunk: a workgroup takes the next RUN of a.run consecutive tiles of its XCD from an atomic
+    // cursor, so one that starts late (another stream's kernel still on its CU) or loses time simply processes fewer runs; inside a
+    // run the next tile is tile + 1 (its left neighbour's carry strips are then in LDS); the cursor value for the tile after a run
+    // is fetched at the top of the run's last tile and travels through LDS (the loop's own barriers order it).
     __shared__ int next_tile_s;
-    if (tid == 0) next_tile_s = t_begin + atomicAdd(&a.xcd_next[xcd], 1);
+    const int run_len = a.run;
+    if (tid == 0) next_tile_s = t_begin + atomicAdd(&a.xcd_next[xcd], run_len);
     __syncthreads();
     int tile = __builtin_amdgcn_readfirstlane(next_tile_s);
     __syncthreads();
     TileId cur = decode(tile < t_end ? tile : 0), nxt = cur;
     if (tile < t_end) issue_input(cur);
-    int rot = 0, tile_nxt = tile;
-    for (; tile < t_end; tile = tile_nxt, cur = nxt, rot++) {
+    int rot = 0, tile_nxt = tile, run_pos = 0;
+    bool follows = false;                   // this tile is the right neighbour of the one this workgroup has just finished, which left its strips
+    bool fed = false;
+    for (; tile < t_end; follows = fed && (tile_nxt == tile + 1), tile = tile_nxt, cur = nxt, rot++) {
         const int f = cur.f, l = cur.l, ty = cur.ty, tx = cur.tx;
         const PLevel& g = a.lv[l];
         const int vrows = (g.oh - ty * TS < TS) ? g.oh - ty * TS : TS;      // valid output rows of this tile
-        int cursor = 0;
-        if (tid == 0) cursor = atomicAdd(&a.xcd_next[xcd], 1);   // in flight during phases 0-2, published at the barrier that ends phase 2
+        const bool carry = follows && tx > 0;                                // consecutive tile index and not a row start: same frame, level, row
+        const bool last_of_run = run_pos + 1 >= run_len;
+        const bool feeds_next = !last_of_run && tx + 1 < g.tiles_x;        // the next tile of the run is this tile's right neighbour
+        fed = feeds_next;
+        int cursor = tile + 1 - t_begin;
+        if (tid == 0 && last_of_run) cursor = atomicAdd(&a.xcd_next[xcd], run_len);   // in flight during phases 0-2, published at the barrier that ends phase 2
+        run_pos = last_of_run ? 0 : run_pos + 1;
 
         // ---- phase 0: prefetched input tile -> RA as [42][42][3] ---------------------------------------------
         if (!(dbg_skip & 16)) {
@@ -540,8 +591,14 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             // one PReLU per pooled cell, never four before the pool.
             // Interior tiles (every conv1 pixel of the tile inside the level) also skip the ceil-mode masks.
             const bool fast = vy >= 2 * P1_T && vx >= 2 * P1_T;
-            auto conv1_pool = [&](auto MODE) {                      // 2: interior + monotone, 1: monotone, 4 / 3: the same with a negative slope
+            // CARRY: pooled columns 0..3 come from the left neighbour (CP, written in its phase 2): only column groups pg = 1..4 are
+            // computed -- 20 M-tiles per wave instead of 25
+            if (carry) copy_pooled(std::false_type{});
+            auto conv1_pool = [&](auto MODE, auto CARRY_T) {        // 2: interior + monotone, 1: monotone, 4 / 3: the same with a negative slope
                 constexpr int kMode = decltype(MODE)::value;
+                constexpr bool CARRY = decltype(CARRY_T)::value;
+                constexpr int NT = CARRY ? 20 : 25;                   // M-tiles of this wave; tile u -> t = 5 i + pg
+                auto tmap = [](int u) { return CARRY ? 5 * (u / 4) + 1 + (u % 4) : u; };
                 float xs[2][14];
                 f32x4 acc[2][2];
                 auto read_tile = [&](int t, float* x) {             // t = 5*i + pg, compile time after unrolling
@@ -578,31 +635,40 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     }
                     if (l15 < 10) RB[c1_lp + i * (4 * P1_T * 10) + pg * 40] = outv;
                 };
-                read_tile(0, xs[0]); read_tile(1, xs[0] + 7);
+                constexpr int NP = (NT + 1) / 2;                      // pairs of M-tiles (the last pair of 25 is a single tile)
+                read_tile(tmap(0), xs[0]); read_tile(tmap(1), xs[0] + 7);
 #pragma unroll
-                for (int jp = 0; jp < 13; jp++) {
+                for (int jp = 0; jp < NP; jp++) {
                     const int cb = jp & 1;
-                    if (jp + 1 < 13) {
-                        read_tile(2 * jp + 2, xs[cb ^ 1]);
-                        if (2 * jp + 3 < 25) read_tile(2 * jp + 3, xs[cb ^ 1] + 7);
+                    const bool two = 2 * jp + 1 < NT;
+                    if (jp + 1 < NP) {
+                        read_tile(tmap(2 * jp + 2), xs[cb ^ 1]);
+                        if (2 * jp + 3 < NT) read_tile(tmap(2 * jp + 3), xs[cb ^ 1] + 7);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // the chain starts from the bias: the first MFMA reads the (never overwritten) bias quad as its C operand
                     // and writes the accumulator -- no per-tile copies of the bias into the accumulator registers
                     acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][0], B1[0], bias1v, 0, 0, 0);
-                    if (jp < 12) acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][7], B1[0], bias1v, 0, 0, 0);
+                    if (two) acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][7], B1[0], bias1v, 0, 0, 0);
 #pragma unroll
                     for (int s = 1; s < 7; s++) {
                         acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][s], B1[s], acc[cb][0], 0, 0, 0);
-                        if (jp < 12) acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][7 + s], B1[s], acc[cb][1], 0, 0, 0);
+                        if (two) acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][7 + s], B1[s], acc[cb][1], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (jp >= 1) { pool_store(acc[cb ^ 1][0], 2 * jp - 2); pool_store(acc[cb ^ 1][1], 2 * jp - 1); }
+                    if (jp >= 1) { pool_store(acc[cb ^ 1][0], tmap(2 * jp - 2)); pool_store(acc[cb ^ 1][1], tmap(2 * jp - 1)); }
                 }
-                pool_store(acc[0][0], 24);
+                // the last pair's epilogue
+                pool_store(acc[(NP - 1) & 1][0], tmap(2 * NP - 2));
+                if (2 * NP - 1 < NT) pool_store(acc[(NP - 1) & 1][1], tmap(2 * NP - 1));
             };
-            if (fast) conv1_pool(std::integral_constant<int, NEG1 ? 4 : 2>{});
-            else conv1_pool(std::integral_constant<int, NEG1 ? 3 : 1>{});
+            if (carry) {
+                if (fast) conv1_pool(std::integral_constant<int, NEG1 ? 4 : 2>{}, std::true_type{});
+                else conv1_pool(std::integral_constant<int, NEG1 ? 3 : 1>{}, std::true_type{});
+            } else {
+                if (fast) conv1_pool(std::integral_constant<int, NEG1 ? 4 : 2>{}, std::false_type{});
+                else conv1_pool(std::integral_constant<int, NEG1 ? 3 : 1>{}, std::false_type{});
+            }
         }
         __syncthreads();
 
@@ -616,7 +682,58 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             // SIMD (wave i of both resident workgroups sits on SIMD i) is the long pole every time.
             const int w2 = (wave + rot) & 3;
             const int lim2 = C2_T * (vrows + 3 < C2_T ? vrows + 3 : C2_T);   // conv2 cells conv3 reads: rows 0 .. vrows+2
+            // the pooled columns the right neighbour will not recompute (RB is read-only during this phase; CP was consumed
+            // before the barrier that ended phase 1)
+            if (feeds_next) copy_pooled(std::true_type{});
             float xa[23], xb[23];
+            if (carry) {
+                // conv2 columns 0..1 come from the left neighbour (CC, written in its phase 3); the 16 new columns of row y are
+                // ONE M-tile: 18 M-tiles (instead of 21), wave role w2 takes rows w2, w2+4, .., every address a lane base + immediate
+                copy_conv2(std::false_type{});
+                const int rows2 = vrows + 3 < C2_T ? vrows + 3 : C2_T;          // conv2 rows conv3 reads
+                const int cbase = (2 + l15) * 10;
+                auto read_rows = [&](int j) {
+                    int yA = w2 + 8 * j;
+                    yA = yA < C2_T ? yA : C2_T - 1;                         // (rows past the tile are not computed: stay inside it)
+                    const int yB = (yA + 4 < C2_T) ? yA + 4 : yA;
+#pragma unroll
+                    for (int s = 0; s < 23; s++) xa[s] = RB[yA * (P1_T * 10) + cbase + koff<30, 170>(s, kq, 0, e2_2, 0)];
+                    if (yA + 4 < C2_T) {
+#pragma unroll
+                        for (int s = 0; s < 23; s++) xb[s] = RB[yB * (P1_T * 10) + cbase + koff<30, 170>(s, kq, 0, e2_2, 0)];
+                    }
+                };
+                read_rows(0);
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int yA = w2 + 8 * j, yB = yA + 4;
+                    const bool hasA = yA < rows2, hasB = yB < rows2;         // (rows2 <= 18: also bounds the row index)
+                    f32x4 accA = bias2v, accB = bias2v;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!hasA) {
+                    } else if (hasB) {
+                        accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0], B2[0], bias2v, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[0], B2[0], bias2v, 0, 0, 0);
+#pragma unroll
+                        for (int s = 1; s < 23; s++) {
+                            accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
+                            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[s], B2[s], accB, 0, 0, 0);
+                        }
+                    } else {
+                        accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0], B2[0], bias2v, 0, 0, 0);
+#pragma unroll
+                        for (int s = 1; s < 23; s++) accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], B2[s], accA, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < 2) read_rows(j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (hasA) RA[(yA * C2_T + 2 + kq * 4 + q) * C2_LD + l15] = prelu_t<UNIT>(accA[q], slope2, sel2);
+                        if (hasB) RA[(yB * C2_T + 2 + kq * 4 + q) * C2_LD + l15] = prelu_t<UNIT>(accB[q], slope2, sel2);
+                    }
+                }
+            } else {
             auto read_pair2 = [&](int j) {
                 const int mtA = w2 + 8 * j, mtB = (mtA + 4 < 21) ? mtA + 4 : mtA;
                 int mA = mtA * 16 + l15; mA = mA < 324 ? mA : 323;
@@ -665,6 +782,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     if (hasB && rb < 324) RA[rb * C2_LD + l15] = prelu_t<UNIT>(accB[q], slope2, sel2);
                 }
             }
+            }   // !carry
         }
         if (tid == 0) next_tile_s = t_begin + cursor;   // the cursor's atomic has had phases 0-2 to return
         __syncthreads();
@@ -674,6 +792,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         if (tile_nxt < t_end) { nxt = decode(tile_nxt); if (!(dbg_skip & 1)) issue_input(nxt); }
 
         // ---- phase 3: conv3 + PReLU -> per-wave staging -> heads -> candidates -------------------------------
+        // the conv2 columns the right neighbour will not recompute (RA is read-only until the barrier that ends the tile)
+        if (feeds_next) copy_conv2(std::true_type{});
         if (!(dbg_skip & 8)) {
             float* ST = RB + wave * 32 * ST_LD;
             const float fscale = g.scale;
@@ -1201,9 +1321,14 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     static const int xlds = getenv("TRL_PNET_XLDS") ? atoi(getenv("TRL_PNET_XLDS")) : 0;   // experiment: unused dynamic LDS, lowers the resident workgroups per CU
     // instantiation: slopes all <= 1 or not, a negative conv1 slope or not, diagnostics (TRL_PNET_CLOCK / TRL_PNET_SKIP) or not
     const bool dbg = c->pnet_clk || a.dbg_skip;
+    // Tiles per cursor fetch: 8 consecutive tiles share 7 carries; small batches keep single tiles so that every CU gets work
+    // (TRL_PNET_RUN / trl_debug_pnet_run override: tuning, and tests that exercise the carry path on small frames)
+    static const int run_env = getenv("TRL_PNET_RUN") ? atoi(getenv("TRL_PNET_RUN")) : 0;
+    const int auto_run = (total_tiles / 8) / 128;
+    a.run = c->pnet_run > 0 ? c->pnet_run : (run_env > 0 ? run_env : (auto_run < 1 ? 1 : (auto_run > 8 ? 8 : auto_run)));
     auto launch = [&](auto kern) {
-        if (xlds > 0) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, xlds);
-        kern<<<grid, 256, xlds, s>>>(a);
+        if (xlds > 0) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DYN_LDS + xlds);
+        kern<<<grid, 256, DYN_LDS + xlds, s>>>(a);
     };
 #define TRL_PK(U, N) do { if (dbg) launch(k_pnet_fused<U, N, true>); else launch(k_pnet_fused<U, N, false>); } while (0)
     if (c->pnet_unit) { if (c->pnet_mono1) TRL_PK(true, false); else TRL_PK(true, true); }

@@ -236,6 +236,10 @@ class Engine:
         _lib.check(self.lib.trl_debug_batch_capacity(self._h, float(t2_per_frame), float(t3_per_frame), C.byref(k)))
         return k.value
 
+    def pnet_run(self, run: int = 0):
+        """Test / tuning hook: tiles per cursor fetch of the fused PNet launch (0 = automatic); > 1 exercises the halo carry."""
+        _lib.check(self.lib.trl_debug_pnet_run(self._h, int(run)))
+
     def stage_totals(self):
         """(boxes that entered R-Net, boxes that entered O-Net) over the whole batch of the last call."""
         t = (C.c_int32 * 2)()

@@ -99,8 +99,11 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
         return outs
 
     # ---- decoupled, grouped embedder ----------------------------------------------------------------------------------
-    emb_eng = embed_engine or engines[0].clone()         # its own context (workspace): the embedder overlaps every cascade
-    es = torch.cuda.Stream(dev)
+    emb_eng = embed_engine or engines[0].clone()         # its own context: its workspace must not alias a cascade's
+    # The embedder call of a group is queued on the stream of the engine that produced the group's LAST batch, i.e. behind that
+    # cascade and in front of that engine's next one -- the position the embedder has inside a per-batch trl_detect_embed.  (A
+    # third stream of its own was measured: same throughput, but its ~100 small launches then interleave with BOTH cascades'
+    # persistent PNet launches and stretch them, 7.1 -> 8.5 ms per launch.)
     S = 80 if engines[0].cfg.embed_mode == 0 else 160
     R = G * ((2 * G + F + G - 1) // G)                   # slots: F being written, G being collected, G being embedded; a multiple
                                                          # of G so that a group never straddles the ring's end
@@ -138,9 +141,10 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
                 deliver(i, out)
             pending.pop(0)
 
-    def flush_group():
+    def flush_group(j):
         if not group:
             return
+        es = streams[j]
         i0, n_full = group[0][0], ring["n"]
         k0 = i0 % R
         cnt = sum(out["valid"].shape[0] for _, out in group)
@@ -168,7 +172,7 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
     done: dict = {}                                      # cascades finished out of batch order wait here
     nxt = [0]                                            # next batch index to join a group
 
-    def collect():
+    def collect(j):
         while nxt[0] in done:
             i = nxt[0]
             out = done.pop(i)
@@ -178,13 +182,13 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
             short = n < ring["n"]
             wraps = (i + 1) % R == 0                     # the next slot is not adjacent in memory
             if len(group) == G or short or wraps or i == K - 1:
-                flush_group()
+                flush_group(j)
 
     for i in range(K):
         j = i % F
         if inflight[j] is not None:
             finish(j)
-            collect()
+            collect(j)
         retire(block_for=i)
         with torch.cuda.stream(streams[j]):              # (the batch source may queue work of its own: NV12 conversion)
             b = get(i, j)
@@ -194,8 +198,8 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
     for k in range(K, K + F):
         if inflight[k % F] is not None:
             finish(k % F)
-            collect()
-    flush_group()
+            collect(k % F)
+    flush_group((K - 1) % F if K else 0)
     while pending:
         retire(block_for=pending[0][2][0][0] + R)        # wait for the oldest call
     return outs
