@@ -426,8 +426,9 @@ def main():
         pnet_s = (pnet_kernel_ms if use_span else pnet_ms) / 1e3 / args.steps
         achieved = 2.0 * macs / pnet_s / 1e12
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "round2_pnet_traffic.json")
-        if eng.cfg.pnet_mode == 0 and args.config == 1 and n == cfg["batch"] and os.path.exists(tpath):
+        tpaths = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pnet_traffic.json"))
+        tpath = os.path.join(ROOT, "profiles", tpaths[-1]) if tpaths else ""      # the newest round's PMC passes
+        if eng.cfg.pnet_mode == 0 and args.config == 1 and n == cfg["batch"] and tpath:
             # HBM bytes per launch of k_pnet_fused from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
         emb_all = d["emb_all"].cpu().numpy()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds profiles/<tag>_* from gpurun_out/refresh/ (written by tools/refresh_profiles.sh on the GPU box).
 
-  python tools/collect_profiles.py [tag]        # tag defaults to round2
+  python tools/collect_profiles.py [tag]        # tag defaults to round3
 """
 import csv
 import json
@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "round3"
 
 
 def pmc_rows(path, counter):
@@ -40,12 +40,14 @@ def main():
     summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), os.path.join(SRC, "stats", "s_kernel_trace.csv"), "2", "--all"],
                           capture_output=True, text=True, check=True).stdout
     open(os.path.join(DST, f"{tag}_step_timeline_inflight1.txt"), "w").write(summ)
-    for name in ("bench_sustained", "bench_config2", "bench_config4", "bench_prelu_general", "bench_ingest_nv12", "bench_gloo2_sharded", "bench_gloo2_streams", "bench_embed_group3"):
+    for name in ("bench_sustained", "bench_config2", "bench_config4", "bench_prelu_general", "bench_prelu_general_inflight1", "bench_ingest_nv12",
+                 "bench_gloo2_sharded", "bench_gloo2_streams", "bench_gloo2_streams_nv12", "bench_embed_group3", "bench_config0", "run_config0",
+                 "bench_driver_threads", "bench_embed_group1", "bench_inflight1_group1", "bench_inflight1_group1_nocarry"):
         src = os.path.join(SRC, name + ".json")
         if os.path.exists(src) and os.path.getsize(src) > 0:
             shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
     for sub, out in (("stats_c2", "config2_kernel_stats_inflight1.csv"), ("stats_c4", "config4_kernel_stats_inflight1.csv"),
-                     ("stats_fn768", "facenet_768faces_kernel_stats.csv")):
+                     ("stats_fn1024", "facenet_1024faces_kernel_stats.csv")):
         src = os.path.join(SRC, sub, "s_kernel_stats.csv")
         if os.path.exists(src):
             shutil.copy(src, os.path.join(DST, f"{tag}_{out}"))

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Regenerates the evidence under gpurun_out/refresh/ that profiles/round2_* is built from.  Run ON the GPU box:
+# Regenerates the evidence under gpurun_out/refresh/ that profiles/round3_* is built from.  Run ON the GPU box:
 #   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh'
-# then, back in the container:  python tools/collect_profiles.py round2
+# then, back in the container:  python tools/collect_profiles.py round3
 # PMC passes are separate runs with --kernel-trace only (never combined with --stats / sys-trace).  The per-step kernel breakdown,
 # the timeline and the PMC passes use one batch in flight (--in-flight 1) so that a step's launches are not interleaved with
 # another context's; the headline bench keeps the default two.
@@ -14,7 +14,15 @@ timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 --in-flight 1 $
 timeout -k 10 300 python bench.py --steps 400 --warmup 5 $B > $O/bench_sustained.json 2> $O/bench_sustained.err; echo "sustained done"
 timeout -k 10 300 python bench.py --config 2 --steps 10 --warmup 2 $B > $O/bench_config2.json 2> $O/bench_config2.err
 timeout -k 10 300 python bench.py --config 4 --steps 6 --warmup 2 $B > $O/bench_config4.json 2> $O/bench_config4.err
-timeout -k 10 300 python bench.py --prelu general --steps 10 $B > $O/bench_prelu_general.json 2> $O/bench_prelu_general.err
+timeout -k 10 300 python bench.py --prelu general --steps 20 --warmup 5 $B > $O/bench_prelu_general.json 2> $O/bench_prelu_general.err
+timeout -k 10 300 python bench.py --prelu general --steps 20 --warmup 5 $B --in-flight 1 > $O/bench_prelu_general_inflight1.json 2> $O/bench_prelu_general_inflight1.err
+timeout -k 10 300 python bench.py --config 0 --steps 20 --warmup 5 > $O/bench_config0.json 2> $O/bench_config0.err
+timeout -k 10 300 python tools/run_wall_time.py $O/run_config0.json > $O/run_config0.log 2>&1
+timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --driver threads --embed-group 1 > $O/bench_driver_threads.json 2> $O/bench_driver_threads.err
+timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --embed-group 1 > $O/bench_embed_group1.json 2> $O/bench_embed_group1.err
+timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --in-flight 1 --embed-group 1 > $O/bench_inflight1_group1.json 2> $O/bench_inflight1_group1.err
+TRL_PNET_RUN=1 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --in-flight 1 --embed-group 1 > $O/bench_inflight1_group1_nocarry.json 2> $O/bench_inflight1_group1_nocarry.err
+timeout -k 10 300 python bench.py --gpus 2 --backend gloo --mode streams --ingest nv12 --steps 6 $B > $O/bench_gloo2_streams_nv12.json 2> $O/bench_gloo2_streams_nv12.err
 timeout -k 10 300 python bench.py --ingest nv12 --steps 10 $B > $O/bench_ingest_nv12.json 2> $O/bench_ingest_nv12.err
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --steps 6 $B > $O/bench_gloo2_sharded.json 2> $O/bench_gloo2_sharded.err
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --mode streams --steps 6 $B > $O/bench_gloo2_streams.json 2> $O/bench_gloo2_streams.err
@@ -31,7 +39,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS
 echo "pmc done"
 timeout -k 10 200 python tools/time_facenet.py 20 256 > $O/facenet_ms.txt 2>&1
 timeout -k 10 200 python tools/time_facenet.py 10 768 >> $O/facenet_ms.txt 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_fn768 -o s -f csv -- python3 tools/time_facenet.py 5 768 > $O/stats_fn768.log 2>&1
-timeout -k 10 300 python bench.py --steps 240 --warmup 6 --embed-group 3 $B > $O/bench_embed_group3.json 2> $O/bench_embed_group3.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_fn1024 -o s -f csv -- python3 tools/time_facenet.py 5 1024 > $O/stats_fn1024.log 2>&1
+timeout -k 10 200 python tools/time_facenet.py 8 1024 >> $O/facenet_ms.txt 2>&1
 timeout -k 10 200 python tools/fn_stamps.py 2 5 16 58 60 61 2>&1 | grep -E "launch|fn stamps" > $O/facenet_stamps.txt
 echo "facenet done"

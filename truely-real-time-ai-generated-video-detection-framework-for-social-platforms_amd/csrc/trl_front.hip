@@ -35,8 +35,11 @@ __device__ __forceinline__ unsigned valid_bytes(int rel, int nbytes) {   // 0xFF
 //       2 = all slopes in [0, 1]: prelu(m) == max(m, s m).
 // The kernel is VALU-bound (crop unpacking, pooling), and VALU shares the FP32 pipe with the f32 MFMAs.
 // DBG: the timing-only phase ablations (TRL_FRONT_SKIP, tools/front_ablation.sh); compiled out of the production instantiation.
+#ifndef TRL_FRONT_MINW
+#define TRL_FRONT_MINW 1      // tuning aid: minimum waves per SIMD the kernel is compiled for (register budget)
+#endif
 template <int S, int C1, int R, int MODE, bool DBG>
-__global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__ frames, int nframes, int H, int W,
+__global__ __launch_bounds__(256, TRL_FRONT_MINW) void k_mtcnn_front(const uint8_t* __restrict__ frames, int nframes, int H, int W,
                                                      const int4* __restrict__ cbox, const int32_t* __restrict__ d_total, int t0,
                                                      const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ s1,
@@ -84,62 +87,85 @@ __global__ __launch_bounds__(256) void k_mtcnn_front(const uint8_t* __restrict__
             for (int p = tid; p < IN_N; p += 256) in_s[p] = 0.f;
         } else if (ih <= 3 * S && iw <= 3 * S) {
             // small boxes: bins of at most 4x4 pixels, i.e. <= 12 bytes per source row = one dword-aligned 16-byte load.
-            // One thread per output pixel, three pixels per pass: all 12 row loads are issued before any is consumed
-            // (one memory round trip per pass instead of one per tap); bytes -> channel sums with v_alignbyte + v_dot4.
-            const long long row_bytes = (long long)W * 3;
-            for (int pb = tid; pb < S * S; pb += 3 * 256) {
-                unsigned ww[3][4][4], shv[3][4];
-                int khv[3], kwv[3];
+            // One thread per output pixel, three pixels per pass: all row loads are issued before any is consumed (one memory
+            // round trip per pass instead of one per tap); bytes -> channel sums with v_alignbyte + v_dot4.
+            // The path is VALU-bound (VALU shares the FP32 pipe with conv1's MFMAs), so: offsets are 32-bit from a scalar,
+            // dword-aligned frame base; only the rows a bin of THIS box can have are fetched (ROWS = 2..4, uniform); the
+            // end-of-buffer clamp runs only for a box at the very end of the last frame; the bin mean uses the exhaustively
+            // verified reciprocal division (bins <= 4x4: far inside its domain) instead of two IEEE divisions per channel.
+            const int fb3 = (int)(fbyte0 & 3);
+            const char* fptr = reinterpret_cast<const char*>(frames) + (fbyte0 - fb3);         // dword aligned, scalar
+            const int row_bytes = W * 3;
+            const int khmax_c = (ih + S - 1) / S + 1;                                        // bins are ceil(ih/S) or one more rows tall
+            // furthest byte any lane can touch: last row of the box, last bin's aligned 16-byte fetch
+            const long long far = fbyte0 + ((long long)(y0 + ih - 1) * W + x0 + iw) * 3 + 16;
+            const bool safe = far <= (long long)nframes * H * W * 3;
+            auto small_pass = [&](auto ROWS_T, auto SAFE_T) {
+                constexpr int ROWS = decltype(ROWS_T)::value;
+                constexpr bool SAFE = decltype(SAFE_T)::value;
+                for (int pb = tid; pb < S * S; pb += 3 * 256) {
+                    unsigned ww[3][ROWS][4], shv[3][ROWS];
+                    int khv[3], kwv[3];
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    const int pp = pb + 256 * u, p = pp < S * S ? pp : 0;
-                    const int oy = p / S, ox = p - oy * S;
-                    const int ys = (oy * ih) / S, ye = ((oy + 1) * ih + S - 1) / S;
-                    const int xs = (ox * iw) / S, xe = ((ox + 1) * iw + S - 1) / S;
-                    khv[u] = ye - ys; kwv[u] = xe - xs;
-                    const long long o0 = fbyte0 + ((long long)(y0 + ys) * W + x0 + xs) * 3;
+                    for (int u = 0; u < 3; u++) {
+                        const int pp = pb + 256 * u, p = pp < S * S ? pp : 0;
+                        const int oy = p / S, ox = p - oy * S;
+                        const int ys = (oy * ih) / S, ye = ((oy + 1) * ih + S - 1) / S;
+                        const int xs = (ox * iw) / S, xe = ((ox + 1) * iw + S - 1) / S;
+                        khv[u] = ye - ys; kwv[u] = xe - xs;
+                        const unsigned lo0 = (unsigned)((y0 + ys) * row_bytes + (x0 + xs) * 3 + fb3);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const long long o = o0 + (long long)(r < khv[u] ? r : (khv[u] > 0 ? khv[u] - 1 : 0)) * row_bytes;
-                        const long long dw = o >> 2;
-                        shv[u][r] = (unsigned)(o & 3);
-                        if (dw + 3 <= last_dw) {
-                            const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(base32 + dw);
-                            ww[u][r][0] = v4[0]; ww[u][r][1] = v4[1]; ww[u][r][2] = v4[2]; ww[u][r][3] = v4[3];
-                        } else {
+                        for (int r = 0; r < ROWS; r++) {
+                            const unsigned lo = lo0 + (unsigned)((r < khv[u] ? r : khv[u] - 1) * row_bytes);     // dead rows re-read the bin's last row
+                            shv[u][r] = lo & 3u;
+                            if (SAFE) {
+                                const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(fptr + (lo & ~3u));
+                                ww[u][r][0] = v4[0]; ww[u][r][1] = v4[1]; ww[u][r][2] = v4[2]; ww[u][r][3] = v4[3];
+                            } else {
+                                const long long dw = ((fbyte0 - fb3) + (long long)(lo & ~3u)) >> 2;
 #pragma unroll
-                            for (int j = 0; j < 4; j++) ww[u][r][j] = base32[dw + j <= last_dw ? dw + j : last_dw];
+                                for (int j = 0; j < 4; j++) ww[u][r][j] = base32[dw + j <= last_dw ? dw + j : last_dw];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        const int nbytes = kwv[u] * 3;
+                        const unsigned vm0 = valid_bytes(0, nbytes), vm1 = valid_bytes(4, nbytes), vm2 = valid_bytes(8, nbytes);
+                        unsigned a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+                        for (int r = 0; r < ROWS; r++) {
+                            const bool live = r < khv[u];
+                            const unsigned sh = shv[u][r];
+                            const unsigned d0 = __builtin_amdgcn_alignbyte(ww[u][r][1], ww[u][r][0], sh) & (live ? vm0 : 0u);
+                            const unsigned d1 = __builtin_amdgcn_alignbyte(ww[u][r][2], ww[u][r][1], sh) & (live ? vm1 : 0u);
+                            const unsigned d2 = __builtin_amdgcn_alignbyte(ww[u][r][3], ww[u][r][2], sh) & (live ? vm2 : 0u);
+                            a0 = __builtin_amdgcn_udot4(d0, 0x01000001u, a0, false); a1 = __builtin_amdgcn_udot4(d0, 0x00000100u, a1, false);
+                            a2 = __builtin_amdgcn_udot4(d0, 0x00010000u, a2, false);
+                            a0 = __builtin_amdgcn_udot4(d1, 0x00010000u, a0, false); a1 = __builtin_amdgcn_udot4(d1, 0x01000001u, a1, false);
+                            a2 = __builtin_amdgcn_udot4(d1, 0x00000100u, a2, false);
+                            a0 = __builtin_amdgcn_udot4(d2, 0x00000100u, a0, false); a1 = __builtin_amdgcn_udot4(d2, 0x00010000u, a1, false);
+                            a2 = __builtin_amdgcn_udot4(d2, 0x01000001u, a2, false);
+                        }
+                        const int pp = pb + 256 * u;
+                        if (pp < S * S) {
+                            // a / kh / kw through the correctly rounded reciprocals of kh, kw in 1..4 (rdiv: equal to the two IEEE
+                            // divisions for every byte sum, oracle/trl_oracle.c orc_selftest_recip_div)
+                            const int kh = khv[u], kw = kwv[u];
+                            const float fkh = (float)kh, fkw = (float)kw;
+                            const float rkh = kh == 3 ? (1.0f / 3.0f) : (kh == 1 ? 1.0f : (kh == 2 ? 0.5f : 0.25f));
+                            const float rkw = kw == 3 ? (1.0f / 3.0f) : (kw == 1 ? 1.0f : (kw == 2 ? 0.5f : 0.25f));
+                            in_s[3 * pp + 0] = (rdiv(rdiv((float)a0, fkh, rkh), fkw, rkw) - 127.5f) * 0.0078125f;
+                            in_s[3 * pp + 1] = (rdiv(rdiv((float)a1, fkh, rkh), fkw, rkw) - 127.5f) * 0.0078125f;
+                            in_s[3 * pp + 2] = (rdiv(rdiv((float)a2, fkh, rkh), fkw, rkw) - 127.5f) * 0.0078125f;
                         }
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    const int nbytes = kwv[u] * 3;
-                    const unsigned vm0 = valid_bytes(0, nbytes), vm1 = valid_bytes(4, nbytes), vm2 = valid_bytes(8, nbytes);
-                    unsigned a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const bool live = r < khv[u];
-                        const unsigned sh = shv[u][r];
-                        const unsigned d0 = __builtin_amdgcn_alignbyte(ww[u][r][1], ww[u][r][0], sh) & (live ? vm0 : 0u);
-                        const unsigned d1 = __builtin_amdgcn_alignbyte(ww[u][r][2], ww[u][r][1], sh) & (live ? vm1 : 0u);
-                        const unsigned d2 = __builtin_amdgcn_alignbyte(ww[u][r][3], ww[u][r][2], sh) & (live ? vm2 : 0u);
-                        a0 = __builtin_amdgcn_udot4(d0, 0x01000001u, a0, false); a1 = __builtin_amdgcn_udot4(d0, 0x00000100u, a1, false);
-                        a2 = __builtin_amdgcn_udot4(d0, 0x00010000u, a2, false);
-                        a0 = __builtin_amdgcn_udot4(d1, 0x00010000u, a0, false); a1 = __builtin_amdgcn_udot4(d1, 0x01000001u, a1, false);
-                        a2 = __builtin_amdgcn_udot4(d1, 0x00000100u, a2, false);
-                        a0 = __builtin_amdgcn_udot4(d2, 0x00000100u, a0, false); a1 = __builtin_amdgcn_udot4(d2, 0x00010000u, a1, false);
-                        a2 = __builtin_amdgcn_udot4(d2, 0x01000001u, a2, false);
-                    }
-                    const int pp = pb + 256 * u;
-                    if (pp < S * S) {
-                        const float kh = (float)khv[u], kw = (float)kwv[u];
-                        in_s[3 * pp + 0] = ((float)a0 / kh / kw - 127.5f) * 0.0078125f;
-                        in_s[3 * pp + 1] = ((float)a1 / kh / kw - 127.5f) * 0.0078125f;
-                        in_s[3 * pp + 2] = ((float)a2 / kh / kw - 127.5f) * 0.0078125f;
-                    }
-                }
-            }
+            };
+            if (!safe) small_pass(std::integral_constant<int, 4>{}, std::false_type{});
+            else if (khmax_c <= 2) small_pass(std::integral_constant<int, 2>{}, std::true_type{});
+            else if (khmax_c == 3) small_pass(std::integral_constant<int, 3>{}, std::true_type{});
+            else small_pass(std::integral_constant<int, 4>{}, std::true_type{});
         } else {
             // big boxes: a wave owns output rows oy = wave (mod 4) and works on TWO of them (oy, oy+4) in lock step, so
             // 32 independent dword loads (2 bins x 4 source rows x 4 chunks) are in flight per round trip -- the crop is

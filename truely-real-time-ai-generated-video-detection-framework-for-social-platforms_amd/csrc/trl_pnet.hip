@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     // run the next tile is tile + 1 (its left neighbour's carry strips are then in LDS); the cursor value for the tile after a run
     // is fetched at the top of the run's last tile and travels through LDS (the loop's own barriers order it).
     __shared__ int next_tile_s;
-    const int run_len = a.run;
+    int run_len = a.run;
     if (tid == 0) next_tile_s = t_begin + atomicAdd(&a.xcd_next[xcd], run_len);
     __syncthreads();
     int tile = __builtin_amdgcn_readfirstlane(next_tile_s);
@@ -565,8 +565,13 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         const bool feeds_next = !last_of_run && tx + 1 < g.tiles_x;        // the next tile of the run is this tile's right neighbour
         fed = feeds_next;
         int cursor = tile + 1 - t_begin;
-        if (tid == 0 && last_of_run) cursor = atomicAdd(&a.xcd_next[xcd], run_len);   // in flight during phases 0-2, published at the barrier that ends phase 2
+        // Guided self-scheduling: near the end of the XCD's chunk the runs shrink (down to single tiles), so the workgroups of an XCD
+        // finish within a tile of each other instead of within a run.  Any run length is correct: a run is whatever atomicAdd hands out.
+        int rem = (t_end - tile - 64 * run_len) >> 7;      // ~ tiles left per pair of workgroups (the cursor runs ~64 runs ahead of this tile)
+        const int next_len = rem < 1 ? 1 : (rem > a.run ? a.run : rem);
+        if (tid == 0 && last_of_run) cursor = atomicAdd(&a.xcd_next[xcd], next_len);   // in flight during phases 0-2, published at the barrier that ends phase 2
         run_pos = last_of_run ? 0 : run_pos + 1;
+        run_len = last_of_run ? next_len : run_len;
 
         // ---- phase 0: prefetched input tile -> RA as [42][42][3] ---------------------------------------------
         if (!(dbg_skip & 16)) {

@@ -8,6 +8,7 @@ drift state machine (model.py:60-66), which consumes their embeddings in order.
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 from typing import Callable, Iterable, List, Sequence
@@ -141,10 +142,20 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
                 deliver(i, out)
             pending.pop(0)
 
+    own = os.environ.get("TRUELY_EMBED_STREAM", "producer")      # experiment: "own" / "own_low" = a third stream (low priority)
+    own_stream = None
+    if own != "producer":
+        lo, hi = -1, 0
+        try:
+            lo, hi = torch.cuda.Stream.priority_range()
+        except Exception:  # noqa: BLE001
+            pass
+        own_stream = torch.cuda.Stream(dev, priority=max(lo, hi)) if own == "own_low" else torch.cuda.Stream(dev)
+
     def flush_group(j):
         if not group:
             return
-        es = streams[j]
+        es = own_stream or streams[j]
         i0, n_full = group[0][0], ring["n"]
         k0 = i0 % R
         cnt = sum(out["valid"].shape[0] for _, out in group)
