@@ -215,14 +215,20 @@ __global__ void k_heads_to_maps(const float* __restrict__ heads, int cells, floa
 }
 
 // ---- stage 1a: per (frame, level) batched_nms(0.5) ------------------------------------------
-__global__ __launch_bounds__(256) void k_nms_level(int L, int cap, const int32_t* __restrict__ lvl_cnt, const Cand* __restrict__ lvl_rec,
+// Two launches share the segments: the SMALL tier (LDS sized for `lds_cap` = 512 candidates: ~24 KB, six workgroups per CU) takes
+// every segment with at most lds_cap candidates -- practically all of them: a level holds ~0.2 % of its cells -- and the FULL tier
+// (LDS for `cap` candidates: 94 KB, one workgroup per CU) only the crowded ones; a workgroup whose segment belongs to the other
+// tier exits at once.  One tier for everything ran the 2,816 segments of a 256-frame batch in eleven rounds of 256.
+__global__ __launch_bounds__(256) void k_nms_level(int L, int cap, int lds_cap, int min_cnt, const int32_t* __restrict__ lvl_cnt,
+                                                   const Cand* __restrict__ lvl_rec,
                                                    int32_t* __restrict__ keep_cnt, int32_t* __restrict__ keep_idx,
                                                    int32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem S(smem_raw, cap);
+    Smem S(smem_raw, lds_cap);
     const int seg = blockIdx.x;
     int cnt = lvl_cnt[seg];
     if (cnt > cap) { cnt = cap; if (threadIdx.x == 0) flags[0] = 1; }
+    if (cnt > lds_cap || cnt < min_cnt) return;                 // the other tier's segment
     if (cnt == 0) { if (threadIdx.x == 0) keep_cnt[seg] = 0; return; }
     const Cand* recs = lvl_rec + (size_t)seg * cap;
     const int P = next_pow2(cnt);
@@ -826,8 +832,16 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     TRL_CHECK(set_dyn_smem(k_nms_frame, sm_f));
     TRL_CHECK(set_dyn_smem(k_stage2_post, sm_f));
     TRL_CHECK(set_dyn_smem(k_stage3_post, sm_f));
-    k_nms_level<<<n * L, 256, sm_l, s>>>(L, cap, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags);
-    TRL_LAUNCH_CHECK();
+    {
+        const int small_cap = cap < 512 ? cap : 512;
+        const size_t sm_s = Smem::bytes(small_cap);
+        k_nms_level<<<n * L, 256, sm_s, s>>>(L, cap, small_cap, 0, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags);
+        TRL_LAUNCH_CHECK();
+        if (small_cap < cap) {
+            k_nms_level<<<n * L, 256, sm_l, s>>>(L, cap, cap, small_cap + 1, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags);
+            TRL_LAUNCH_CHECK();
+        }
+    }
     k_nms_frame<<<n, 256, sm_f, s>>>(L, cap, capF, W, H, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.n1, B.s1_box, B.flags);
     TRL_LAUNCH_CHECK();
 
