@@ -52,6 +52,7 @@ class Engine:
         if blob is None:
             blob = _weights.synthetic_blob(0)   # no checkpoints exist offline
         self._blob = blob
+        self._pending = None                 # (outputs, frames) of the call queued by detect_embed_begin
         _lib.check(self.lib.trl_load_weights(self._h, blob, len(blob)))
 
     def clone(self) -> "Engine":
@@ -156,6 +157,8 @@ class Engine:
 
     def detect_embed_end(self):
         """Finish the call queued by :meth:`detect_embed_begin`: the one host synchronisation, the capacity check and (rarely) the re-run."""
+        if self._pending is None:
+            raise RuntimeError("detect_embed_end() without a call queued by detect_embed_begin()")
         out, _fr = self._pending
         try:
             _lib.check(self.lib.trl_detect_embed_end(self._h))

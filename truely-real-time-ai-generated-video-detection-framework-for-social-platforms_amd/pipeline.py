@@ -100,7 +100,9 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
         return outs
 
     # ---- decoupled, grouped embedder ----------------------------------------------------------------------------------
-    emb_eng = embed_engine or engines[0].clone()         # its own context: its workspace must not alias a cascade's
+    emb_eng = embed_engine or getattr(engines[0], "_embedder", None)
+    if emb_eng is None:                                  # its own context (its workspace must not alias a cascade's), built once
+        emb_eng = engines[0]._embedder = engines[0].clone()
     # The embedder call of a group is queued on the stream of the engine that produced the group's LAST batch, i.e. behind that
     # cascade and in front of that engine's next one -- the position the embedder has inside a per-batch trl_detect_embed.  (A
     # third stream of its own was measured: same throughput, but its ~100 small launches then interleave with BOTH cascades'
@@ -152,6 +154,8 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
             pass
         own_stream = torch.cuda.Stream(dev, priority=max(lo, hi)) if own == "own_low" else torch.cuda.Stream(dev)
 
+    last_embed = [None]                                  # event behind the most recent embedder call
+
     def flush_group(j):
         if not group:
             return
@@ -165,9 +169,13 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
             faces = ring["faces"].view(R * n_full, S, S, 3)[k0 * n_full:k0 * n_full + cnt]
             valid = ring["valid"].view(R * n_full)[k0 * n_full:k0 * n_full + cnt]
         with torch.cuda.stream(es):                      # the crops are complete: their cascades were synchronised by _end
+            if last_embed[0] is not None:
+                es.wait_event(last_embed[0])             # the embedder context has ONE workspace: its calls run one after the
+                                                         # other even when consecutive groups end on different engines' streams
             emb = emb_eng.embed_faces(faces, valid)      # queues ~100 launches and returns
             ev = torch.cuda.Event()
             ev.record(es)
+        last_embed[0] = ev
         pending.append((ev, emb, list(group)))
         group.clear()
 
