@@ -1,5 +1,7 @@
 """One-off fuzz beyond the test suite: random frame shapes / contents through the whole cascade against the oracle.
-python tools/fuzz_shapes.py [cases] [seed]     (GPU box; prints the first mismatch and exits 1)"""
+python tools/fuzz_shapes.py [cases] [seed] [pnet_run] [slopes]     (GPU box; prints the first mismatch and exits 1)
+pnet_run > 0 forces the fused PNet kernel's tile runs (its halo-carry path) on these small frames; slopes = "general" uses the
+generalised PReLU slopes (above 1 and negative: the med3 / min+max pooling instantiations)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,8 +11,13 @@ from oracle.oracle import Oracle
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-blob = truely_amd.weights.synthetic_blob(0)
+run = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if len(sys.argv) > 4 and sys.argv[4] == "general":
+    blob = truely_amd.weights.pack_state_dicts(*truely_amd.weights.generalise_prelu(list(truely_amd.weights.synthetic_state_dicts(0))))
+else:
+    blob = truely_amd.weights.synthetic_blob(0)
 eng, orc = Engine(blob, cap_level=3072, cap_frame=3072), Oracle(blob)
+eng.pnet_run(run)
 rng = np.random.default_rng(seed)
 for t in range(cases):
     H, W, n = int(rng.integers(20, 420)), int(rng.integers(20, 560)), int(rng.integers(1, 4))
