@@ -402,7 +402,7 @@ template <bool UNIT, bool NEG1, bool DBG>
 __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
-    __shared__ float HSall[4 * 32 * 9];                           // per-wave head outputs [32 cells][9]
+    __shared__ float HSall[4 * 32 * 2];                           // per wave: reg2, reg3 of its 32 cells (the other head outputs stay in registers)
     extern __shared__ __attribute__((aligned(16))) float DYN[];  // DYN_LDS bytes, then whatever a tuning run pads (TRL_PNET_XLDS)
     float* const B3S = DYN;                                       // conv3 weights [k][cout]: read per k-chain batch, not held in VGPRs
     float* const CP = DYN + 144 * 32;                             // carried pooled columns [20][4][10]
@@ -417,20 +417,21 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 
     // ---- B operands: every weight matrix stays in registers for the whole launch -----------------------------
     for (int i = tid; i < 144 * 32; i += 256) B3S[i] = a.w3[i];          // conv3 B operand [k][32] in LDS (18 KB)
-    float B1[7], B2[23], BH[8];
+    float B1[7], B2[23], WH[4];
 #pragma unroll
     for (int s = 0; s < 7; s++) B1[s] = a.w1[(4 * s + kq) * 32 + l15];
 #pragma unroll
     for (int s = 0; s < 23; s++) B2[s] = a.w2[(4 * s + kq) * 32 + l15];
 #pragma unroll
-    for (int s = 0; s < 8; s++) BH[s] = a.wh[(4 * s + kq) * 32 + l15];
+    for (int r = 0; r < 4; r++) WH[r] = a.wh[(((lane >> 2) & 7) + 8 * r) * 32 + 4 * (lane >> 5) + (lane & 3)];   // heads: see phase 3
+    const int hcell = lane & 31;                                 // == 4 ((lane >> 2) & 7) + (lane & 3)
     const float bias1 = a.b1[l15], slope1 = a.s1[l15];   // vectors are zero padded to 128 floats
     const float bias2 = a.b2[l15], slope2 = a.s2[l15];
     const float bias3 = a.b3[l31], slope3 = a.s3[l31];
-    const float biash = a.bh[l15];
+    const f32x4 biasq = {a.bh[4 * (lane >> 5)], a.bh[4 * (lane >> 5) + 1], a.bh[4 * (lane >> 5) + 2], a.bh[4 * (lane >> 5) + 3]};
     // general instantiation only: the per-channel med3 selector (+inf: max(v, s v), -inf: min(v, s v)); dead code when UNIT
     const float sel1 = trl_prelu_sel(slope1), sel2 = trl_prelu_sel(slope2), sel3 = trl_prelu_sel(slope3);
-    const f32x4 bias1v = {bias1, bias1, bias1, bias1}, bias2v = {bias2, bias2, bias2, bias2}, biashv = {biash, biash, biash, biash};
+    const f32x4 bias1v = {bias1, bias1, bias1, bias1}, bias2v = {bias2, bias2, bias2, bias2};
 
     // LDS beyond the live tiles is read by zero-weight k padding: it must hold finite values
     for (int i = tid; i < REGION_A; i += 256) RA[i] = 0.f;
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             }
         }
     };
-    float* const HS = HSall + wave * 32 * 9;
+    float* const HS = HSall + wave * 32 * 2;
     // Carry strips <-> tiles, a handful of instructions per tile (VALU beside the MFMAs is paid in matrix throughput): the pooled
     // strip is 20 rows x 40 floats = 10 float4 per row (16 threads per row, 10 active: rows 0..15 in one pass, 16..19 in a second);
     // the conv2 strip is 18 rows x 34 floats = 17 float2 per row (32 threads per row, 17 active: three passes).
@@ -837,29 +838,26 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     ST[row * ST_LD + l31] = prelu_t<UNIT>(acc[q], slope3, sel3);
                 }
                 __builtin_amdgcn_wave_barrier();
-                // heads: two 16-row M-tiles, K = 32
-                f32x4 hA, hB;
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    const float xa = ST[l15 * ST_LD + 4 * s + kq];
-                    const float xb = ST[(16 + l15) * ST_LD + 4 * s + kq];
-                    hA = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, BH[s], s == 0 ? biashv : hA, 0, 0, 0);
-                    hB = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, BH[s], s == 0 ? biashv : hB, 0, 0, 0);
-                }
-                // lane (n = l15, rows kq*4+q): n=0,1 class logits, n=2..5 box regression -> [row][9] staging
-                if (l15 < 6) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        HS[(kq * 4 + q) * 9 + l15] = hA[q];
-                        HS[(16 + kq * 4 + q) * 9 + l15] = hB[q];
-                    }
-                }
+                // heads (1x1, 32 -> 2 + 4) on v_mfma_f32_4x4x1_16B_f32: sixteen 4x4 blocks per instruction, ONE k per instruction.
+                // Block b of lanes 4b..4b+3 = cells 4(b & 7) .. +3 (the B operand: the cell's conv3 value at k), outputs
+                // 4(b >> 3) .. +3 (the A operand: weights W[k][4(b >> 3) + i], broadcast inside each group of eight blocks from block
+                // k & 7 of register k >> 3 -- cbsz = 3, abid = k & 7): one instruction does both output groups of all 32 cells,
+                // 32 instructions x 8 cycles = half the issue time of two 16-row 16x16x4 tiles whose N = 6 is padded to 16, and
+                // every lane ends up holding ITS cell's logits (no transposing staging).  Same chain: acc = bias, k ascending.
+                f32x4 hq = biasq;
+#define TRL_HSTEP(k) hq = __builtin_amdgcn_mfma_f32_4x4x1f32(WH[(k) >> 3], ST[hcell * ST_LD + (k)], hq, 3, (k) & 7, 0);
+                TRL_HSTEP(0) TRL_HSTEP(1) TRL_HSTEP(2) TRL_HSTEP(3) TRL_HSTEP(4) TRL_HSTEP(5) TRL_HSTEP(6) TRL_HSTEP(7)
+                TRL_HSTEP(8) TRL_HSTEP(9) TRL_HSTEP(10) TRL_HSTEP(11) TRL_HSTEP(12) TRL_HSTEP(13) TRL_HSTEP(14) TRL_HSTEP(15)
+                TRL_HSTEP(16) TRL_HSTEP(17) TRL_HSTEP(18) TRL_HSTEP(19) TRL_HSTEP(20) TRL_HSTEP(21) TRL_HSTEP(22) TRL_HSTEP(23)
+                TRL_HSTEP(24) TRL_HSTEP(25) TRL_HSTEP(26) TRL_HSTEP(27) TRL_HSTEP(28) TRL_HSTEP(29) TRL_HSTEP(30) TRL_HSTEP(31)
+#undef TRL_HSTEP
+                // lanes 0..31: {logit0, logit1, reg0, reg1} of cell = lane; lanes 32..63: {reg2, reg3, -, -} of cell = lane - 32
+                if (lane >= 32) { HS[2 * hcell] = hq[0]; HS[2 * hcell + 1] = hq[1]; }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 32) {                            // one lane per cell of the 32-row tile
                     const int oy = ty * TS + mt * 2 + (lane >> 4), ox = tx * TS + (lane & 15);
                     if (oy < g.oh && ox < g.ow) {
-                        const float* hv = HS + lane * 9;
-                        const float p = trl_softmax2_p1(hv[0], hv[1]);
+                        const float p = trl_softmax2_p1(hq[0], hq[1]);
                         if (p >= a.thr && !(dbg_skip & 32)) {      // (bit 32: timing-only ablations emit no candidates)
                             const int seg = f * a.L + l;
                             const int sl = atomicAdd(&a.lvl_cnt[seg], 1);
@@ -870,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                                 c.x2 = floorf((2.f * (float)ox + 12.f) / fscale);
                                 c.y2 = floorf((2.f * (float)oy + 12.f) / fscale);
                                 c.score = p;
-                                c.r0 = hv[2]; c.r1 = hv[3]; c.r2 = hv[4]; c.r3 = hv[5];
+                                c.r0 = hq[2]; c.r1 = hq[3]; c.r2 = HS[2 * lane]; c.r3 = HS[2 * lane + 1];
                                 c.cell = oy * g.ow + ox;
                                 a.lvl_rec[(size_t)seg * a.cap + sl] = c;
                             } else {
