@@ -3,8 +3,9 @@
     python tools/kernel_resources.py [filter]      # exits 1 if any kernel uses scratch (spills)
 
 hipcc embeds one gfx950 code object per translation unit in the .so's .hip_fatbin section (clang offload bundles); their
-AMDGPU metadata notes are printed with llvm-readelf.  Every hand-written kernel is expected to have
-private_segment_fixed_size == 0."""
+AMDGPU metadata notes are printed with llvm-readelf.  Every PRODUCTION kernel is expected to have
+private_segment_fixed_size == 0; the diagnostic instantiations of k_pnet_fused (last template argument true:
+clock stamps + phase ablations, selected by TRL_PNET_CLOCK / TRL_PNET_SKIP only) are reported but may spill a few registers."""
 import os
 import re
 import struct
@@ -60,5 +61,6 @@ if __name__ == "__main__":
         if flt and flt not in dem:
             continue
         print(f"{dem[:110]:110s} vgpr {k['vgpr']:3d} agpr {k['agpr']:3d} sgpr {k['sgpr']:3d} lds {k['lds']:6d} scratch {k['scratch']}")
-        bad += k["scratch"] > 0
+        diagnostic = "k_pnet_fused<" in dem and dem.split(">(")[0].endswith("true")
+        bad += k["scratch"] > 0 and not diagnostic
     sys.exit(1 if bad else 0)

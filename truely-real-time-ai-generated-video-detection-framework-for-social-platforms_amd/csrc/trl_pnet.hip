@@ -11,16 +11,16 @@
 //
 //  k_pnet_fused   ONE persistent launch over all (frame, level, 16x16-cell tile) work items.  Per tile,
 //                 entirely in LDS / registers:
-//                   42x42x3 input tile -> conv1 3x3 (3->10) + PReLU + 2x2 ceil max-pool (in the MFMA
-//                   epilogue: the 4 rows a lane holds ARE one pool window) -> conv2 3x3 (10->16) + PReLU
+//                   42x42x3 input tile -> conv1 3x3 (3->10) + 2x2 ceil max-pool + PReLU (the pool is an
+//                   elementwise max over accumulators, or two DPP steps) -> conv2 3x3 (10->16) + PReLU
 //                   -> conv3 3x3 (16->32) + PReLU -> 1x1 heads (32->2+4) -> softmax -> thr0 ->
 //                   generateBoundingBox record appended to the (frame, level) candidate list.
-//                 All four layers run on the f32 matrix cores (v_mfma_f32_16x16x4_f32 for N<=16,
-//                 v_mfma_f32_32x32x2_f32 for conv3), k ascending, accumulator seeded with the bias: the
-//                 same fmaf chain as the oracle, so maps and candidates are bit-identical.
-//                 conv1 / conv2 / head weights live in registers for the whole launch (B operands: 7+23+8
-//                 VGPRs per lane), conv3's in LDS; activations never leave the CU: HBM traffic is the pyramid
-//                 read only.  f32 MFMA and VALU share the FP32 pipe, so the loops carry almost no VALU: the
+//                 All four layers run on the f32 matrix cores -- the layers with few output channels (conv1: 10, heads: 6)
+//                 on v_mfma_f32_4x4x1_16B_f32 with the weight block broadcast (no padding of N to 16), conv2 on
+//                 v_mfma_f32_16x16x4_f32, conv3 on v_mfma_f32_32x32x2_f32 -- k ascending, accumulator seeded with the
+//                 bias: the same fmaf chain as the oracle, so maps and candidates are bit-identical.
+//                 conv1 / conv2 / head weights live in registers for the whole launch (6+23+4 VGPRs per lane),
+//                 conv3's in LDS; activations never leave the CU: HBM traffic is the pyramid read only.  f32 MFMA and VALU share the FP32 pipe, so the loops carry almost no VALU: the
 //                 tile decode is scalar (multiply-high by host magic numbers), LDS addresses are lane bases +
 //                 compile-time offsets, pooling precedes PReLU when the slopes allow, edge logic only on edge tiles.
 //                 blockIdx -> tile mapping keeps an XCD on a contiguous run of tiles (halo rows of
@@ -395,6 +395,53 @@ __device__ __forceinline__ float prelu_pooled_t(float m, float n, float sl, floa
     return UNIT ? vmax_nc(m, sl * (sl < 0.f ? n : m)) : trl_prelu_pooled(m, n, sl, sel);
 }
 
+// ---- conv1 on v_mfma_f32_4x4x1_16B_f32 -----------------------------------------------------------------------------------------
+// 16x16x4 tiles pad conv1's N = 10 to 16 (and K = 27 to 28): 40 % of their issue cycles multiply zeros.  The 4x4x1 block
+// instruction computes sixteen independent 4x4 outer-product blocks, ONE k per instruction, and can broadcast block `abid` of the A
+// register to all sixteen (cbsz = 4).  A UNIT = 16 pool cells x their 4 conv1 positions: block b = cell, lane-in-block j = position
+// (dy, dx); the B operand is the lane's pixel value at k; the A operand is W[k][4 cg + i] for one of three channel groups, broadcast
+// from block k & 15 of register k >> 4 -- the whole 27 x 12 weight matrix (+ the bias as a 28th "k" against a constant 1) lives in
+// 6 VGPRs.  84 instructions x 8 cycles per 64 pixels instead of 4 x 7 x 32: -25 % issue cycles; the chain per output is still
+// acc = bias, k ascending (fma(bias, 1, 0) == bias exactly).  The 2x2 pool window of a cell is the block's four lanes: two DPP max.
+template <int CB, int AB>
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, CB, AB, 0); }
+// max / min over the four lanes of each quad, four values at a time; one asm block per group so that no DPP instruction reads a
+// register written by one of the two instructions in front of it (gfx9 DPP hazard) whatever the scheduler does around the block
+__device__ __forceinline__ void quad_max4(const f32x4& v, float (&o)[4]) {
+    float t0, t1, t2, t3;
+    asm("v_max_f32_dpp %4, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %5, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %6, %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %7, %11, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+}
+__device__ __forceinline__ void quad_min4(const f32x4& v, float (&o)[4]) {
+    float t0, t1, t2, t3;
+    asm("v_min_f32_dpp %4, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %5, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %6, %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %7, %11, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %0, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %1, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %2, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %3, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+}
+// per-lane select on a wave-uniform 64-bit lane mask (one v_cndmask: hipcc turned the ?: on lane-index tests into exec-mask branches)
+__device__ __forceinline__ float lane_sel(float if0, float if1, unsigned long long mask) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+    return r;
+}
+template <int... I, typename F>
+__device__ __forceinline__ void pn_static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
 // DBG: diagnostic instantiation -- records the launch's execution span on the device wall clock (TRL_PNET_CLOCK=1) and honours
 // the timing-only phase ablation mask (TRL_PNET_SKIP, tools/pnet_phase_pmc.sh).  The production instantiation (DBG = false)
 // carries neither: no instrumentation and no ablation tests on the hot path.
@@ -417,35 +464,47 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
 
     // ---- B operands: every weight matrix stays in registers for the whole launch -----------------------------
     for (int i = tid; i < 144 * 32; i += 256) B3S[i] = a.w3[i];          // conv3 B operand [k][32] in LDS (18 KB)
-    float B1[7], B2[23], WH[4];
-#pragma unroll
-    for (int s = 0; s < 7; s++) B1[s] = a.w1[(4 * s + kq) * 32 + l15];
+    float B2[23], WH[4];
 #pragma unroll
     for (int s = 0; s < 23; s++) B2[s] = a.w2[(4 * s + kq) * 32 + l15];
 #pragma unroll
     for (int r = 0; r < 4; r++) WH[r] = a.wh[(((lane >> 2) & 7) + 8 * r) * 32 + 4 * (lane >> 5) + (lane & 3)];   // heads: see phase 3
     const int hcell = lane & 31;                                 // == 4 ((lane >> 2) & 7) + (lane & 3)
-    const float bias1 = a.b1[l15], slope1 = a.s1[l15];   // vectors are zero padded to 128 floats
+    // (vectors are zero padded to 128 floats)
     const float bias2 = a.b2[l15], slope2 = a.s2[l15];
     const float bias3 = a.b3[l31], slope3 = a.s3[l31];
     const f32x4 biasq = {a.bh[4 * (lane >> 5)], a.bh[4 * (lane >> 5) + 1], a.bh[4 * (lane >> 5) + 2], a.bh[4 * (lane >> 5) + 3]};
     // general instantiation only: the per-channel med3 selector (+inf: max(v, s v), -inf: min(v, s v)); dead code when UNIT
-    const float sel1 = trl_prelu_sel(slope1), sel2 = trl_prelu_sel(slope2), sel3 = trl_prelu_sel(slope3);
-    const f32x4 bias1v = {bias1, bias1, bias1, bias1}, bias2v = {bias2, bias2, bias2, bias2};
+    const float sel2 = trl_prelu_sel(slope2), sel3 = trl_prelu_sel(slope3);
+    const f32x4 bias2v = {bias2, bias2, bias2, bias2};
 
     // LDS beyond the live tiles is read by zero-weight k padding: it must hold finite values
     for (int i = tid; i < REGION_A; i += 256) RA[i] = 0.f;
     for (int i = tid; i < REGION_B; i += 256) RB[i] = 0.f;
     __syncthreads();
 
-    // conv1 rows: i = pool cell (i>>2) x sub-position (i&3) of a 4-cell group
-    const int c1_pc = l15 >> 2, c1_dy = (l15 >> 1) & 1, c1_dx = l15 & 1;
-    // conv1 A-operand lane bases (k = 4s+kq walks a [42][3]-strided 3x3x3 patch: row step 126-9 = 117 floats once
-    // 4s+kq passes a multiple of 9) and the pooled-cell store base; everything else is an immediate offset.
-    const int c1_la0 = ((2 * wave + c1_dy) * IN_T + 2 * c1_pc + c1_dx) * 3 + kq;
-    const int c1_la1 = c1_la0 + (kq >= 1 ? 117 : 0), c1_la2 = c1_la0 + (kq >= 2 ? 117 : 0), c1_la3 = c1_la0 + (kq >= 3 ? 117 : 0);
-    const int c1_lp = (wave * P1_T + kq) * 10 + l15;
     const int e2_2 = kq >= 2 ? 170 : 0;                                                      // conv2: D = 30, E = 200-30
+    // conv1 on 4x4x1 blocks: block xb = pool cell of the unit, xj = (dy, dx); weights + bias of channel group cg packed 16 k per register
+    const int xb = lane >> 2, xj = lane & 3, xdy = xj >> 1, xdx = xj & 1;
+    float WC[3][2];
+#pragma unroll
+    for (int cg = 0; cg < 3; cg++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int k = xb + 16 * h;
+            WC[cg][h] = k < 27 ? a.w1[k * 32 + 4 * cg + xj] : (k == 27 ? a.b1[4 * cg + xj] : 0.f);
+        }
+    float xone = 1.0f;
+    asm volatile("" : "+v"(xone));                        // a VGPR holding 1.0 (the bias "k"): not re-materialised per use
+    const int xcg = xj < 3 ? xj : 2;                      // lane j < 3 finishes channel group j of its cell (lane 3 idles in the epilogue)
+    const float sl4[4] = {a.s1[4 * xcg], a.s1[4 * xcg + 1], a.s1[4 * xcg + 2], a.s1[4 * xcg + 3]};
+    // wide unit of pooled row wave + 4 i, columns 4..19: input lane base and store base (+ immediates per i)
+    const int c1x_w = ((2 * wave + xdy) * IN_T + 8 + 2 * xb + xdx) * 3;
+    const int c1x_sw = (wave * P1_T + 4 + xb) * 10 + 4 * xj;
+    // SUPER unit: the 64 cells (row wave + 4 j, column 4 + xb), ONE conv1 position per pass: the pool window is then four
+    // accumulators of the SAME lane (no cross-lane step), and every lane finishes its own cell
+    const int c1s_l = ((2 * wave + 8 * xj) * IN_T + 8 + 2 * xb) * 3;
+    const int c1s_s = ((wave + 4 * xj) * P1_T + 4 + xb) * 10;
 
     const int total_tiles = a.tiles_per_frame * a.n_frames;
     // XCD-aware persistent schedule: blocks sharing blockIdx%8 (one XCD) walk one contiguous 1/8 of the tiles
@@ -584,12 +643,13 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         }
         __syncthreads();
 
-        // ---- phase 1: conv1 + PReLU + 2x2 ceil max-pool -> RB as [20][20][10] ------------------------------
-        // 100 M-tiles (5 groups of 4 pool cells per pooled row).  Wave w owns pooled rows w, w+4, .., w+16 (25
-        // M-tiles), so every LDS address is a per-wave lane base plus a COMPILE-TIME offset: the fully unrolled
-        // sequence spends no VALU on addressing (VALU and f32 MFMA share the FP32 pipe).  Tiles run as pairs of
-        // independent accumulator chains; the A operands of pair j+1 are read before the MFMAs of pair j issue
-        // and the pool epilogue of pair j-1 runs behind them.
+        // ---- phase 1: conv1 + 2x2 ceil max-pool + PReLU -> RB as [20][20][10] ------------------------------
+        // conv1 (3 -> 10 channels, K = 27) runs on the 4x4x1 block instruction (see mfma4 above): wave w owns pooled rows w, w+4,
+        // .., w+16.  Rows w .. w+12 x the 16 columns a carrying tile computes are ONE super unit of 64 cells (lane = cell, one
+        // conv1 position per pass, the pool = an elementwise max of the four passes' accumulators); the fifth row and -- in a tile
+        // without a left neighbour -- columns 0..3 run as quad units (block = cell, lanes = the four positions, pool = two DPP max).
+        // Every LDS address is a per-lane base plus a compile-time offset; 420 block instructions of 8 cycles per wave and carry
+        // tile against 20 x 7 16x16x4 instructions of 32 cycles before (N = 10 padded to 16, K = 27 to 28).
         if (!(dbg_skip & 2)) {
             const int vy = g.h - 2 - ty * 2 * TS, vx = g.w - 2 - tx * 2 * TS;   // valid conv1 extent inside the tile
             // max-pool commutes with PReLU when the slope is >= 0 (monotone): pool first, one PReLU per cell.  With a negative
@@ -600,80 +660,158 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             // CARRY: pooled columns 0..3 come from the left neighbour (CP, written in its phase 2): only column groups pg = 1..4 are
             // computed -- 20 M-tiles per wave instead of 25
             if (carry) copy_pooled(std::false_type{});
-            auto conv1_pool = [&](auto MODE, auto CARRY_T) {        // 2: interior + monotone, 1: monotone, 4 / 3: the same with a negative slope
-                constexpr int kMode = decltype(MODE)::value;
-                constexpr bool CARRY = decltype(CARRY_T)::value;
-                constexpr int NT = CARRY ? 20 : 25;                   // M-tiles of this wave; tile u -> t = 5 i + pg
-                auto tmap = [](int u) { return CARRY ? 5 * (u / 4) + 1 + (u % 4) : u; };
-                float xs[2][14];
-                f32x4 acc[2][2];
-                auto read_tile = [&](int t, float* x) {             // t = 5*i + pg, compile time after unrolling
-                    const int off = (t / 5) * (8 * IN_T * 3) + (t % 5) * 24;
-#pragma unroll
-                    for (int s = 0; s < 7; s++) {
-                        const int thr = 9 - (4 * s) % 9;            // koff<9,117>: which lane-dependent row step applies
-                        const int la = thr == 1 ? c1_la1 : (thr == 2 ? c1_la2 : (thr == 3 ? c1_la3 : c1_la0));
-                        x[s] = RA[la + off + 4 * s + 117 * ((4 * s) / 9)];
-                    }
-                };
-                auto pool_store = [&](const f32x4& v, int t) {
-                    const int i = t / 5, pg = t % 5;
-                    float outv;
-                    const int py = wave + 4 * i;
-                    const bool r0 = 2 * py < vy, r1 = 2 * py + 1 < vy;
-                    const bool c0 = 8 * pg + 2 * kq < vx, c1 = 8 * pg + 2 * kq + 1 < vx;
-                    if (kMode == 2) {
-                        const float m = vmax_nc(vmax3_nc(v[0], v[1], v[2]), v[3]);
-                        outv = prelu_t<UNIT>(m, slope1, sel1);
-                    } else if (kMode == 4) {
-                        const float m = vmax_nc(vmax3_nc(v[0], v[1], v[2]), v[3]), n = vmin_nc(vmin3_nc(v[0], v[1], v[2]), v[3]);
-                        outv = prelu_pooled_t<UNIT>(m, n, slope1, sel1);
-                    } else {                                          // ceil-mode window clipped by the level edge
-                        const float ninf = -__builtin_inff();         // (dy,dx) = (0,0) is valid whenever the cell is
-                        const bool k1 = r0 && c1, k2 = r1 && c0, k3 = r1 && c1;
-                        const float m = fmaxf(fmaxf(v[0], k1 ? v[1] : ninf), fmaxf(k2 ? v[2] : ninf, k3 ? v[3] : ninf));
-                        if (kMode == 1) {
-                            outv = (r0 && c0) ? prelu_t<UNIT>(m, slope1, sel1) : 0.f;
-                        } else {
-                            const float n = fminf(fminf(v[0], k1 ? v[1] : -ninf), fminf(k2 ? v[2] : -ninf, k3 ? v[3] : -ninf));
-                            outv = (r0 && c0) ? prelu_pooled_t<UNIT>(m, n, slope1, sel1) : 0.f;
-                        }
-                    }
-                    if (l15 < 10) RB[c1_lp + i * (4 * P1_T * 10) + pg * 40] = outv;
-                };
-                constexpr int NP = (NT + 1) / 2;                      // pairs of M-tiles (the last pair of 25 is a single tile)
-                read_tile(tmap(0), xs[0]); read_tile(tmap(1), xs[0] + 7);
-#pragma unroll
-                for (int jp = 0; jp < NP; jp++) {
-                    const int cb = jp & 1;
-                    const bool two = 2 * jp + 1 < NT;
-                    if (jp + 1 < NP) {
-                        read_tile(tmap(2 * jp + 2), xs[cb ^ 1]);
-                        if (2 * jp + 3 < NT) read_tile(tmap(2 * jp + 3), xs[cb ^ 1] + 7);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the chain starts from the bias: the first MFMA reads the (never overwritten) bias quad as its C operand
-                    // and writes the accumulator -- no per-tile copies of the bias into the accumulator registers
-                    acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][0], B1[0], bias1v, 0, 0, 0);
-                    if (two) acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][7], B1[0], bias1v, 0, 0, 0);
-#pragma unroll
-                    for (int s = 1; s < 7; s++) {
-                        acc[cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][s], B1[s], acc[cb][0], 0, 0, 0);
-                        if (two) acc[cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cb][7 + s], B1[s], acc[cb][1], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (jp >= 1) { pool_store(acc[cb ^ 1][0], tmap(2 * jp - 2)); pool_store(acc[cb ^ 1][1], tmap(2 * jp - 1)); }
-                }
-                // the last pair's epilogue
-                pool_store(acc[(NP - 1) & 1][0], tmap(2 * NP - 2));
-                if (2 * NP - 1 < NT) pool_store(acc[(NP - 1) & 1][1], tmap(2 * NP - 1));
+            // Units of this wave: the wide units (columns 4..19) of its five pooled rows wave + 4 i; a tile that does not carry also
+            // computes columns 0..3 as five NARROW units (4 rows x 4 columns each): narrow unit `wave` goes to this wave, narrow unit 4
+            // to one wave in turn.  Units run in pairs (six independent accumulator chains keep the 8-cycle instruction issuing back to
+            // back); the loop is not unrolled -- four instantiations of the body (edge masks x one / two units) instead of the old
+            // path's four fully unrolled 25-tile sequences keeps the kernel's code inside the instruction cache.
+            struct XU { int lb, sb, row, col; };
+            auto wide_u = [&](int i) { XU u; u.lb = c1x_w + i * (8 * IN_T * 3); u.sb = c1x_sw + i * (4 * P1_T * 10); u.row = wave + 4 * i; u.col = 4 + xb; return u; };
+            auto narrow_u = [&](int n) {
+                XU u; u.row = 4 * n + (xb >> 2); u.col = xb & 3;
+                u.lb = ((2 * u.row + xdy) * IN_T + 2 * u.col + xdx) * 3; u.sb = (u.row * P1_T + u.col) * 10 + 4 * xj;
+                return u;
             };
-            if (carry) {
-                if (fast) conv1_pool(std::integral_constant<int, NEG1 ? 4 : 2>{}, std::true_type{});
-                else conv1_pool(std::integral_constant<int, NEG1 ? 3 : 1>{}, std::true_type{});
-            } else {
-                if (fast) conv1_pool(std::integral_constant<int, NEG1 ? 4 : 2>{}, std::false_type{});
-                else conv1_pool(std::integral_constant<int, NEG1 ? 3 : 1>{}, std::false_type{});
+            auto x_epi = [&](auto EDGE_T, const XU& u, const f32x4 (&acc)[3]) {
+                constexpr bool EDGE = decltype(EDGE_T)::value;
+                const float ninf = -__builtin_inff();
+                const bool pv = !EDGE || ((2 * u.row + xdy < vy) && (2 * u.col + xdx < vx));     // this lane's conv1 pixel lies inside the level
+                float m[3][4], n[3][4];
+#pragma unroll
+                for (int cg = 0; cg < 3; cg++) {
+                    f32x4 v = acc[cg];
+                    if (EDGE) { v[0] = pv ? v[0] : ninf; v[1] = pv ? v[1] : ninf; v[2] = pv ? v[2] : ninf; v[3] = pv ? v[3] : ninf; }
+                    quad_max4(v, m[cg]);
+                    if (NEG1) {
+                        f32x4 w = acc[cg];
+                        if (EDGE) { w[0] = pv ? w[0] : -ninf; w[1] = pv ? w[1] : -ninf; w[2] = pv ? w[2] : -ninf; w[3] = pv ? w[3] : -ninf; }
+                        quad_min4(w, n[cg]);
+                    }
+                }
+                const bool cv = !EDGE || ((2 * u.row < vy) && (2 * u.col < vx));                 // the cell exists (its (0,0) pixel does)
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float pm = lane_sel(lane_sel(m[2][r], m[1][r], 0x2222222222222222ull), m[0][r], 0x1111111111111111ull);   // lane j: group j
+                    const float sel = UNIT ? 0.f : trl_prelu_sel(sl4[r]);
+                    if (NEG1) {
+                        const float pn = lane_sel(lane_sel(n[2][r], n[1][r], 0x2222222222222222ull), n[0][r], 0x1111111111111111ull);
+                        o[r] = prelu_pooled_t<UNIT>(pm, pn, sl4[r], sel);
+                    } else {
+                        o[r] = prelu_t<UNIT>(pm, sl4[r], sel);
+                    }
+                    if (EDGE) o[r] = cv ? o[r] : 0.f;
+                }
+                if (xj < 3) {                                    // lane j stores channels 4j .. 4j+3 of its cell (j = 2: channels 8, 9)
+                    *reinterpret_cast<f32x2c*>(RB + u.sb) = f32x2c{o[0], o[1]};
+                    if (xj < 2) *reinterpret_cast<f32x2c*>(RB + u.sb + 2) = f32x2c{o[2], o[3]};
+                }
+            };
+            auto x_units = [&](auto EDGE_T, auto HASB_T, const XU& A, const XU& B) {
+                constexpr bool HASB = decltype(HASB_T)::value;
+                f32x4 accA[3], accB[3];
+                float xa[2][9], xc[2][9];
+                auto rd = [&](int t, float* xo, int lb) {        // k = 9 t + u sits at lb + 126 t + u of the [42][42][3] tile
+#pragma unroll
+                    for (int u = 0; u < 9; u++) xo[u] = RA[lb + 126 * t + u];
+                };
+                rd(0, xa[0], A.lb);
+                if (HASB) rd(0, xc[0], B.lb);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cg = 0; cg < 3; cg++) {                 // the chain starts at the bias: slot k = 27 of the weight registers x 1.0
+                    accA[cg] = mfma4<4, 11>(WC[cg][1], xone, z);
+                    if (HASB) accB[cg] = mfma4<4, 11>(WC[cg][1], xone, z);
+                }
+                pn_static_for(std::make_integer_sequence<int, 3>{}, [&](auto T) __attribute__((always_inline)) {
+                    constexpr int t = decltype(T)::value;
+                    if (t < 2) { rd(t + 1, xa[(t + 1) & 1], A.lb); if (HASB) rd(t + 1, xc[(t + 1) & 1], B.lb); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    pn_static_for(std::make_integer_sequence<int, 9>{}, [&](auto UU) __attribute__((always_inline)) {
+                        constexpr int u = decltype(UU)::value, k = 9 * t + u;
+#pragma unroll
+                        for (int cg = 0; cg < 3; cg++) {
+                            accA[cg] = mfma4<4, (k & 15)>(WC[cg][k >> 4], xa[t & 1][u], accA[cg]);
+                            if (HASB) accB[cg] = mfma4<4, (k & 15)>(WC[cg][k >> 4], xc[t & 1][u], accB[cg]);
+                        }
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                x_epi(EDGE_T, A, accA);
+                if (HASB) x_epi(EDGE_T, B, accB);
+            };
+            // Rows wave, wave+4, wave+8, wave+12 x columns 4..19 as ONE super unit: pass p computes conv1 position (dy, dx) = (p >> 1, p & 1)
+            // of all 64 cells (lane = cell); two passes run interleaved (six chains), the pool is an elementwise max of the passes'
+            // accumulators -- 24 VALU per 64 cells where four quad units spend 96 DPP max and 32 selects -- and each lane applies the
+            // PReLU to, and stores, its own cell's ten channels.
+            auto x_super = [&](auto EDGE_T) {
+                constexpr bool EDGE = decltype(EDGE_T)::value;
+                const float ninf = -__builtin_inff();
+                const int srow = wave + 4 * xj, scol = 4 + xb;
+                f32x4 mx[3], mn[3];
+                pn_static_for(std::make_integer_sequence<int, 2>{}, [&](auto PP) __attribute__((always_inline)) {
+                    constexpr int pp = decltype(PP)::value;      // passes 2 pp (dx = 0) and 2 pp + 1 (dx = 1) of conv1 row parity dy = pp
+                    const int lbA = c1s_l + pp * (IN_T * 3), lbB = lbA + 3;
+                    f32x4 accA[3], accB[3];
+                    float xa[2][9], xc[2][9];
+                    auto rd = [&](int t, float* xo, int lb) {
+#pragma unroll
+                        for (int u = 0; u < 9; u++) xo[u] = RA[lb + 126 * t + u];
+                    };
+                    rd(0, xa[0], lbA); rd(0, xc[0], lbB);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int cg = 0; cg < 3; cg++) { accA[cg] = mfma4<4, 11>(WC[cg][1], xone, z); accB[cg] = mfma4<4, 11>(WC[cg][1], xone, z); }
+                    pn_static_for(std::make_integer_sequence<int, 3>{}, [&](auto T) __attribute__((always_inline)) {
+                        constexpr int t = decltype(T)::value;
+                        if (t < 2) { rd(t + 1, xa[(t + 1) & 1], lbA); rd(t + 1, xc[(t + 1) & 1], lbB); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        pn_static_for(std::make_integer_sequence<int, 9>{}, [&](auto UU) __attribute__((always_inline)) {
+                            constexpr int u = decltype(UU)::value, k = 9 * t + u;
+#pragma unroll
+                            for (int cg = 0; cg < 3; cg++) {
+                                accA[cg] = mfma4<4, (k & 15)>(WC[cg][k >> 4], xa[t & 1][u], accA[cg]);
+                                accB[cg] = mfma4<4, (k & 15)>(WC[cg][k >> 4], xc[t & 1][u], accB[cg]);
+                            }
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    const bool pvA = !EDGE || ((2 * srow + pp < vy) && (2 * scol < vx)), pvB = !EDGE || ((2 * srow + pp < vy) && (2 * scol + 1 < vx));
+#pragma unroll
+                    for (int cg = 0; cg < 3; cg++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float va = EDGE ? (pvA ? accA[cg][r] : ninf) : accA[cg][r], vb = EDGE ? (pvB ? accB[cg][r] : ninf) : accB[cg][r];
+                            mx[cg][r] = pp == 0 ? vmax_nc(va, vb) : vmax3_nc(mx[cg][r], va, vb);
+                            if (NEG1) {
+                                const float wa = EDGE ? (pvA ? accA[cg][r] : -ninf) : accA[cg][r], wb = EDGE ? (pvB ? accB[cg][r] : -ninf) : accB[cg][r];
+                                mn[cg][r] = pp == 0 ? vmin_nc(wa, wb) : vmin3_nc(mn[cg][r], wa, wb);
+                            }
+                        }
+                });
+                const bool cv = !EDGE || ((2 * srow < vy) && (2 * scol < vx));
+                float o[12];
+#pragma unroll
+                for (int c = 0; c < 10; c++) {
+                    const float sl = a.s1[c];                    // uniform: a scalar load, the multiply takes it as an SGPR operand
+                    const float sel = UNIT ? 0.f : trl_prelu_sel(sl);
+                    o[c] = NEG1 ? prelu_pooled_t<UNIT>(mx[c >> 2][c & 3], mn[c >> 2][c & 3], sl, sel) : prelu_t<UNIT>(mx[c >> 2][c & 3], sl, sel);
+                    if (EDGE) o[c] = cv ? o[c] : 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 10; c += 2) *reinterpret_cast<f32x2c*>(RB + c1s_s + c) = f32x2c{o[c], o[c + 1]};
+            };
+            if (fast) x_super(std::false_type{}); else x_super(std::true_type{});
+            // ... the fifth row (wave + 16) and, in a tile that does not carry, the narrow units as quad units (pool = the block's lanes)
+            const int extra_wave = rot & 3;                      // the wave that takes narrow unit 4 of a tile that does not carry
+#pragma unroll 1
+            for (int pr = 2; pr < 4; pr++) {
+                if (pr == 3 && (carry || wave != extra_wave)) break;
+                const XU A = pr < 3 ? wide_u(4) : narrow_u(4);
+                const XU B = narrow_u(wave);
+                const bool two = pr == 2 && !carry;
+                if (fast) { if (two) x_units(std::false_type{}, std::true_type{}, A, B); else x_units(std::false_type{}, std::false_type{}, A, B); }
+                else { if (two) x_units(std::true_type{}, std::true_type{}, A, B); else x_units(std::true_type{}, std::false_type{}, A, B); }
             }
         }
         __syncthreads();
