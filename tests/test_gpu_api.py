@@ -501,3 +501,23 @@ def test_large_embedder_batches_cross_kernel_families(engine, oracle):
     env = dict(os.environ, TRL_NO_FNCONV="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
+
+
+def test_overlapped_pipeline_recovers_from_a_failed_call(blob):
+    """A crowded batch overflows a candidate list (TRL_ERR_CAPACITY: an error, never a truncation) in the middle of an overlapped
+    run: the exception propagates, every engine's queued call is finished on the way out, and the same engines work again."""
+    from truely_amd._lib import TrlError
+    from truely_amd.engine import Engine
+    from truely_amd.pipeline import detect_embed_overlapped
+    engs = [Engine(blob, cap_level=64, cap_frame=64) for _ in range(2)]
+    good = truely_amd.synthetic.synthetic_frames(2, 97, 131, seed=1)
+    noisy = np.random.default_rng(0).integers(0, 256, (2, 180, 320, 3), dtype=np.uint8)   # far more than 64 candidates per level
+    for G in (1, 2):
+        with pytest.raises(TrlError) as ei:
+            detect_embed_overlapped(engs, [good, good, noisy, good, good], embed_group=G)
+        assert ei.value.status == -4
+        outs = detect_embed_overlapped(engs, [good, good, good], embed_group=G)          # no "call in flight" left behind
+        assert len(outs) == 3
+    ref = Engine(blob).detect_embed(good)
+    outs = detect_embed_overlapped([Engine(blob), Engine(blob)], [good, good], embed_group=2)
+    assert torch.equal(outs[1]["emb"], ref["emb"])

@@ -50,10 +50,14 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
 
     ``embed_group`` = G > 1: the embedder is decoupled from the batches.  The cascades write their crops into consecutive slots
     of a ring; every G consecutive batches (in batch order, whichever engine produced them) are embedded by ONE
-    ``trl_facenet_embed_masked`` call on ``embed_engine``'s own stream while the next batches are being detected.
-    InceptionResnetV1 at the reference's 80x80 crops is ~100 small dependent launches whose fixed cost amortises over the faces
-    of a call: 2.22 ms per 256 faces at 256 per call, 1.78 ms (42.7 % of the f32-MFMA peak) at 768.  Every output element is the
-    same accumulation chain whatever the grouping: results are bit-identical to per-batch ``detect_embed``.
+    ``trl_facenet_embed_masked`` call of ``embed_engine`` (a context of its own, created and cached on first use), queued behind
+    the cascade that produced the group's last batch.  InceptionResnetV1 at the reference's 80x80 crops is ~100 small dependent
+    launches whose fixed cost amortises over the faces of a call: 2.16 ms per 256 faces at 256 per call, 1.70 ms at 768, 1.60 ms
+    (47.6 % of the f32-MFMA peak) at 1,024.  Every output element is the same accumulation chain whatever the grouping: results
+    are bit-identical to per-batch ``detect_embed``.
+
+    If a call fails (a capacity overflow in a crowded batch, an allocation failure) the calls still queued on the other engines are
+    finished before the exception propagates, so every engine can be used again.
 
     ``batches``: a sequence, or a callable ``(i, j) -> batch`` with ``n_batches`` (the bench's NV12 uploader prefetches per engine).
     ``on_detect(i, j)`` is called when batch i's cascade has finished on engine j (timing hooks); ``on_result(i, out)`` in batch
@@ -77,26 +81,40 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
             on_result(i, out)
         outs.append(out)
 
+    def abandon():
+        """An exception is propagating: finish whatever is still queued so that no engine stays 'busy'."""
+        for j in range(F):
+            if inflight[j] is not None:
+                try:
+                    with torch.cuda.stream(streams[j]):
+                        engines[j].detect_embed_end()
+                except Exception:  # noqa: BLE001 - the first error is the one the caller sees
+                    pass
+                inflight[j] = None
+
     if G == 1:
         def finish(j):
-            i = inflight[j]
+            i, inflight[j] = inflight[j], None           # (whatever _end does, the call is over)
             with torch.cuda.stream(streams[j]):
                 out = engines[j].detect_embed_end()      # synchronises stream j: the tensors are safe to use on any stream
-            inflight[j] = None
             if on_detect:
                 on_detect(i, j)
             deliver(i, out)
 
-        for i in range(K):
-            j = i % F
-            if inflight[j] is not None:
-                finish(j)
-            with torch.cuda.stream(streams[j]):
-                engines[j].detect_embed_begin(get(i, j))
-            inflight[j] = i
-        for k in range(K, K + F):                        # drain in batch order
-            if inflight[k % F] is not None:
-                finish(k % F)
+        try:
+            for i in range(K):
+                j = i % F
+                if inflight[j] is not None:
+                    finish(j)
+                with torch.cuda.stream(streams[j]):
+                    engines[j].detect_embed_begin(get(i, j))
+                inflight[j] = i
+            for k in range(K, K + F):                    # drain in batch order
+                if inflight[k % F] is not None:
+                    finish(k % F)
+        except BaseException:
+            abandon()
+            raise
         return outs
 
     # ---- decoupled, grouped embedder ----------------------------------------------------------------------------------
@@ -180,10 +198,9 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
         group.clear()
 
     def finish(j):
-        i = inflight[j]
+        i, inflight[j] = inflight[j], None
         with torch.cuda.stream(streams[j]):
             out = engines[j].detect_embed_end()
-        inflight[j] = None
         if on_detect:
             on_detect(i, j)
         done[i] = out
@@ -203,24 +220,30 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
             if len(group) == G or short or wraps or i == K - 1:
                 flush_group(j)
 
-    for i in range(K):
-        j = i % F
-        if inflight[j] is not None:
-            finish(j)
-            collect(j)
-        retire(block_for=i)
-        with torch.cuda.stream(streams[j]):              # (the batch source may queue work of its own: NV12 conversion)
-            b = get(i, j)
-            fv, vv = slot_views(i, int(b.shape[0]))
-            engines[j].detect_embed_begin(b, crop=True, faces=fv, valid=vv)
-        inflight[j] = i
-    for k in range(K, K + F):
-        if inflight[k % F] is not None:
-            finish(k % F)
-            collect(k % F)
-    flush_group((K - 1) % F if K else 0)
-    while pending:
-        retire(block_for=pending[0][2][0][0] + R)        # wait for the oldest call
+    try:
+        for i in range(K):
+            j = i % F
+            if inflight[j] is not None:
+                finish(j)
+                collect(j)
+            retire(block_for=i)
+            with torch.cuda.stream(streams[j]):          # (the batch source may queue work of its own: NV12 conversion)
+                b = get(i, j)
+                fv, vv = slot_views(i, int(b.shape[0]))
+                engines[j].detect_embed_begin(b, crop=True, faces=fv, valid=vv)
+            inflight[j] = i
+        for k in range(K, K + F):
+            if inflight[k % F] is not None:
+                finish(k % F)
+                collect(k % F)
+        flush_group((K - 1) % F if K else 0)
+        while pending:
+            retire(block_for=pending[0][2][0][0] + R)    # wait for the oldest call
+    except BaseException:
+        abandon()
+        if last_embed[0] is not None:
+            last_embed[0].synchronize()                  # the embedder's queued launches read the ring: let them end before it is freed
+        raise
     return outs
 
 
