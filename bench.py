@@ -415,6 +415,18 @@ def main():
     else:
         scores = [int(d["score"])]
 
+    # After the timed region (never part of `value`): the dominant kernel alone -- a few strictly sequential steps on one context,
+    # nothing else queued on the GPU -- so the line also carries the launch duration free of the queueing that two cascades in
+    # flight add to the event pair above (the committed `--in-flight 1` rocprofv3 stats show the same number).
+    iso_ms = None
+    if rank == 0 and eng.cfg.pnet_mode == 0 and frames is not None:
+        torch.cuda.synchronize()
+        tot = 0.0
+        for _ in range(4):
+            eng.detect_embed(frames)
+            tot += eng.timings()["pnet_ms"]
+        iso_ms = tot / 4
+
     if rank == 0:
         tm = eng.timings()
         macs = pnet_macs(H, W, cfg["min_face"]) * n                  # per launch set of one step on this rank
@@ -458,6 +470,8 @@ def main():
                          "flop_per_step": 2.0 * macs, "kernel_ms_per_step": round(pnet_s * 1e3, 3), "launches_per_step": launches,
                          "kernel_clock": "device wall clock span of the launch" if use_span else "HIP events",
                          "kernel_ms_per_step_hip_events": round(pnet_ms / args.steps, 3),
+                         "kernel_ms_alone": None if iso_ms is None else round(iso_ms, 3),
+                         "frac_alone": None if iso_ms is None else round(2.0 * macs / (iso_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                          "pyramid_ms_per_step": round(pyr_ms / args.steps, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
