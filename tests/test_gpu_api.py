@@ -521,3 +521,23 @@ def test_overlapped_pipeline_recovers_from_a_failed_call(blob):
     ref = Engine(blob).detect_embed(good)
     outs = detect_embed_overlapped([Engine(blob), Engine(blob)], [good, good], embed_group=2)
     assert torch.equal(outs[1]["emb"], ref["emb"])
+
+
+def test_batches_beyond_16k_frames(blob):
+    """check_call admits up to 65,535 frames per call; the exclusive scan of the per-frame candidate counts used to need (n + 1) x 4 B of
+    dynamic LDS (a launch failure past 16,383 frames).  17,000 tiny frames in ONE call: the results of the first and last frames
+    equal those of a small call on the same frames (batch independence), faceless frames stay faceless."""
+    from truely_amd.engine import Engine
+    eng = Engine(blob, cap_level=64, cap_frame=64)
+    rng = np.random.default_rng(4)
+    n = 17000
+    fr = (rng.integers(0, 256, (n, 24, 28, 3)) // 8 + 112).astype(np.uint8)
+    face = truely_amd.synthetic.synthetic_frames(4, 24, 28, seed=9)
+    fr[:4] = face
+    fr[-4:] = face
+    out = eng.detect_embed(fr)
+    small = eng.detect_embed(np.concatenate([fr[:6], fr[-6:]]))
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        got = torch.cat([out[k][:6], out[k][-6:]])
+        assert torch.equal(got, small[k]), k
+    assert out["valid"].shape[0] == n
