@@ -541,3 +541,35 @@ def test_batches_beyond_16k_frames(blob):
         got = torch.cat([out[k][:6], out[k][-6:]])
         assert torch.equal(got, small[k]), k
     assert out["valid"].shape[0] == n
+
+
+def test_run_decodes_and_writes_mjpeg_avi(engine, oracle, tmp_path, monkeypatch):
+    """`run()` on a COMPRESSED clip, both ends, without OpenCV: the input is a Motion-JPEG AVI file (decoded frame by frame through
+    `AviMjpegReader` inside run's own loop), the annotated output lands at a path named like the server's (`*_output.mp4`) as a
+    Motion-JPEG AVI stream.  The score is the oracle's for the frames the decoder yields; the output holds every frame, at the
+    input's rate and size, and reads back (it was written after annotation, so sampled frames with a face differ from the input
+    only inside / around the drawn box)."""
+    from truely_amd import engine as eng_mod, model, video_io
+    if video_io.cv2 is not None:
+        pytest.skip("OpenCV present: run() takes the cv2 path for .avi / .mp4")
+    monkeypatch.setattr(eng_mod, "_default", engine)
+    H, W, fps, N = 180, 320, 30, 36
+    fr = truely_amd.synthetic.synthetic_frames(N, H, W, seed=3)
+    src, dst = str(tmp_path / "clip.avi"), str(tmp_path / "clip_output.mp4")
+    w = video_io.AviMjpegWriter(src, fps, (W, H), quality=92)
+    for f in fr:
+        w.write(f)
+    w.release()
+    rd, rfps, rw, rh = video_io.open_reader(src)
+    assert isinstance(rd, video_io.AviMjpegReader) and (rfps, rw, rh, rd.n) == (fps, W, H, N)
+    decoded = np.stack([rd.read()[1] for _ in range(N)])
+    rd.release()
+    score = model.run(src, dst)
+    r = oracle.detect_embed(decoded[::4])                              # model.py:40,46: every 4th frame at 30 fps
+    d = oracle.drift_score(r["emb"], r["valid"], N, fps)
+    assert score == d["score"]
+    out, ofps, ow, oh = video_io.open_reader(dst)
+    assert isinstance(out, video_io.AviMjpegReader) and (ofps, ow, oh, out.n) == (fps, W, H, N)
+    ok, first = out.read()
+    assert ok and first.shape == (H, W, 3)
+    assert os.path.getsize(dst) < decoded.nbytes // 3                   # bounded: a fraction of the raw frames
