@@ -342,6 +342,98 @@ __global__ __launch_bounds__(256, TRL_FRONT_MINW) void k_mtcnn_front(const uint8
     float* dst = out + (size_t)blockIdx.x * P * P * C1;
     float* const erow = c1_s + (kq * 4) * CLD + l15;             // epilogue lane base: row 4*kq (+q), channel l15
     if (dbg_skip & 2) return;
+    constexpr int C4 = C1 / 4;
+    // the pooled value's PReLU (slope classes: see MODE) and the store, shared by both strip schemes
+    auto finish_pool = [&](float4 best, float4 low, int c4, int pr_abs, int px) __attribute__((always_inline)) {
+        const float4 sl = *reinterpret_cast<const float4*>(s1 + 4 * c4);
+        if (MODE == 2) {
+            best.x = vmax_nc(best.x, sl.x * best.x); best.y = vmax_nc(best.y, sl.y * best.y);
+            best.z = vmax_nc(best.z, sl.z * best.z); best.w = vmax_nc(best.w, sl.w * best.w);
+        } else if (MODE == 1) {
+            best.x = trl_prelu_med3(best.x, sl.x, trl_prelu_sel(sl.x)); best.y = trl_prelu_med3(best.y, sl.y, trl_prelu_sel(sl.y));
+            best.z = trl_prelu_med3(best.z, sl.z, trl_prelu_sel(sl.z)); best.w = trl_prelu_med3(best.w, sl.w, trl_prelu_sel(sl.w));
+        } else {
+            best.x = trl_prelu_pooled(best.x, low.x, sl.x, trl_prelu_sel(sl.x)); best.y = trl_prelu_pooled(best.y, low.y, sl.y, trl_prelu_sel(sl.y));
+            best.z = trl_prelu_pooled(best.z, low.z, sl.z, trl_prelu_sel(sl.z)); best.w = trl_prelu_pooled(best.w, low.w, sl.w, trl_prelu_sel(sl.w));
+        }
+        *reinterpret_cast<float4*>(dst + ((size_t)pr_abs * P + px) * C1 + 4 * c4) = best;
+    };
+    if constexpr (R == 1 && C1 == 32) {
+        // ONE pooled row per strip (the O-Net front: three workgroups per CU) WITHOUT recomputing the conv row two consecutive pool
+        // windows share: conv row r lives in slot r % 3 of a three-row ring, a strip computes the two rows its window adds (three for
+        // the first strip) instead of three -- a third of the conv work of the plain strip scheme -- and every M-tile lies inside
+        // one conv row (3 tiles of 16 pixels, the row padded to 48), so the 6 tiles x 2 channel halves split evenly: each wave runs
+        // three independent chains of ONE half (its B operand: 7 registers), 21 matrix instructions per strip where the plain scheme's
+        // busiest wave issued 42.
+        constexpr int RW = 48;                                   // padded conv row (3 M-tiles)
+        static_assert(3 * RW * CLD <= MROWS * CLD, "ring fits the strip buffer");
+        const int half = wave & 1, tsel = wave >> 1;             // this wave: channel half, tiles tsel, tsel + 2, ...
+        float Bh[7];
+#pragma unroll
+        for (int s = 0; s < 7; s++) Bh[s] = half ? B1[s] : B0[s];
+        const float biash = half ? bias1 : bias0;
+        for (int p0 = 0; p0 < P; p0++) {
+            const int r_first = p0 == 0 ? 0 : 2 * p0 + 1;
+            const int r_last = 2 * p0 + 2 < CW ? 2 * p0 + 2 : CW - 1;
+            const int ntl = (r_last - r_first + 1) * 3;          // tiles of this strip: tile t -> conv row r_first + t / 3, pixels 16 (t % 3) ..
+            for (int t0 = tsel; t0 < ntl; t0 += 6) {             // up to three tiles of this wave at a time: t0, t0 + 2, t0 + 4
+                f32x4 acc[3];
+                float xa[3][7];
+                int srow[3], x0[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int t = t0 + 2 * u < ntl ? t0 + 2 * u : t0;          // (a missing tile repeats the first: computed, not stored)
+                    const int row = r_first + t / 3;
+                    x0[u] = 16 * (t - 3 * (t / 3));
+                    srow[u] = row - 3 * (row / 3);
+                    int x = x0[u] + l15; x = x < CW ? x : CW - 1;
+                    const int base = (row * S + x) * 3;
+#pragma unroll
+                    for (int s = 0; s < 7; s++) xa[u][s] = in_s[base + koff[s]];
+                    acc[u] = f32x4{biash, biash, biash, biash};
+                }
+#pragma unroll
+                for (int s = 0; s < 7; s++)
+#pragma unroll
+                    for (int u = 0; u < 3; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][s], Bh[s], acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    if (t0 + 2 * u < ntl) {
+                        float* e = c1_s + (srow[u] * RW + x0[u] + 4 * kq) * CLD + 16 * half + l15;     // pixels past CW land in the row's padding
+#pragma unroll
+                        for (int q = 0; q < 4; q++) e[q * CLD] = acc[u][q];
+                    }
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < P * C4; idx += 256) {
+                const int c4 = idx % C4, px = idx / C4;
+                const int rA = 2 * p0, rB = rA + 1, rC = rA + 2;            // the window's conv rows (rC may lie below the map)
+                const float* sA = c1_s + ((rA - 3 * (rA / 3)) * RW + 2 * px) * CLD + 4 * c4;
+                const float* sB = c1_s + ((rB - 3 * (rB / 3)) * RW + 2 * px) * CLD + 4 * c4;
+                const float* sC = c1_s + ((rC - 3 * (rC / 3)) * RW + 2 * px) * CLD + 4 * c4;
+                float4 best = *reinterpret_cast<const float4*>(sA), low = best;
+                const bool x2 = 2 * px + 2 < CW;
+                const int nrw = rC < CW ? 3 : (rB < CW ? 2 : 1);
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    if (dy >= nrw) break;
+                    const float* sr = dy == 0 ? sA : (dy == 1 ? sB : sC);
+#pragma unroll
+                    for (int dx = 0; dx < 3; dx++) {
+                        if (dy == 0 && dx == 0) continue;
+                        if (dx == 2 && !x2) continue;
+                        const float4 v = *reinterpret_cast<const float4*>(sr + dx * CLD);
+                        best.x = vmax_nc(best.x, v.x); best.y = vmax_nc(best.y, v.y); best.z = vmax_nc(best.z, v.z); best.w = vmax_nc(best.w, v.w);
+                        if (MODE == 0) { low.x = vmin_nc(low.x, v.x); low.y = vmin_nc(low.y, v.y); low.z = vmin_nc(low.z, v.z); low.w = vmin_nc(low.w, v.w); }
+                    }
+                }
+                finish_pool(best, low, c4, p0, px);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int p0 = 0; p0 < P; p0 += R) {
         const int rows0 = 2 * p0;
         const int nrows = (CW - rows0) < SR ? (CW - rows0) : SR;
@@ -396,7 +488,6 @@ __global__ __launch_bounds__(256, TRL_FRONT_MINW) void k_mtcnn_front(const uint8
         __syncthreads();
         // ---- MaxPool(3, 2, ceil_mode) of the strip -> global NHWC [P][P][C1], four channels per thread ------------
         const int prow = (P - p0) < R ? (P - p0) : R;
-        constexpr int C4 = C1 / 4;
         for (int idx = tid; idx < prow * P * C4; idx += 256) {
             const int c4 = idx % C4;
             const int px = (idx / C4) % P;
@@ -432,20 +523,7 @@ __global__ __launch_bounds__(256, TRL_FRONT_MINW) void k_mtcnn_front(const uint8
                     }
                 }
             }
-            {
-                const float4 sl = *reinterpret_cast<const float4*>(s1 + 4 * c4);
-                if (MODE == 2) {
-                    best.x = vmax_nc(best.x, sl.x * best.x); best.y = vmax_nc(best.y, sl.y * best.y);
-                    best.z = vmax_nc(best.z, sl.z * best.z); best.w = vmax_nc(best.w, sl.w * best.w);
-                } else if (MODE == 1) {
-                    best.x = trl_prelu_med3(best.x, sl.x, trl_prelu_sel(sl.x)); best.y = trl_prelu_med3(best.y, sl.y, trl_prelu_sel(sl.y));
-                    best.z = trl_prelu_med3(best.z, sl.z, trl_prelu_sel(sl.z)); best.w = trl_prelu_med3(best.w, sl.w, trl_prelu_sel(sl.w));
-                } else {
-                    best.x = trl_prelu_pooled(best.x, low.x, sl.x, trl_prelu_sel(sl.x)); best.y = trl_prelu_pooled(best.y, low.y, sl.y, trl_prelu_sel(sl.y));
-                    best.z = trl_prelu_pooled(best.z, low.z, sl.z, trl_prelu_sel(sl.z)); best.w = trl_prelu_pooled(best.w, low.w, sl.w, trl_prelu_sel(sl.w));
-                }
-            }
-            *reinterpret_cast<float4*>(dst + ((size_t)(p0 + pr) * P + px) * C1 + 4 * c4) = best;
+            finish_pool(best, low, c4, p0 + pr, px);
         }
         __syncthreads();
     }
