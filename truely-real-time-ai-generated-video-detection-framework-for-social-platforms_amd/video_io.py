@@ -295,7 +295,7 @@ class AviMjpegReader:
             p += 8 + csz + (csz & 1)
 
     def _walk_movi(self, pos, end):
-        while pos + 8 <= end and len(self.frames) < 10_000_000:
+        while pos + 8 <= end and len(self.frames) < 4_000_000:      # (37 h at 30 fps: anything longer is a damaged or hostile file)
             self.f.seek(pos)
             cid, csz = struct.unpack("<4sI", self.f.read(8))
             if cid == b"LIST":                       # 'rec ' groups
