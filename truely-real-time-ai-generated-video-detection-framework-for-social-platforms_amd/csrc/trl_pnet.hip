@@ -449,7 +449,7 @@ template <bool UNIT, bool NEG1, bool DBG>
 __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
-    __shared__ float HSall[4 * 32 * 2];                           // per wave: reg2, reg3 of its 32 cells (the other head outputs stay in registers)
+    __shared__ __attribute__((aligned(16))) float T3all[64];      // conv3 bias[32], PReLU slopes[32]: a lane's 16 channels differ per register (phase 3)
     extern __shared__ __attribute__((aligned(16))) float DYN[];  // DYN_LDS bytes, then whatever a tuning run pads (TRL_PNET_XLDS)
     float* const B3S = DYN;                                       // conv3 weights [k][cout]: read per k-chain batch, not held in VGPRs
     float* const CP = DYN + 144 * 32;                             // carried pooled columns [20][4][10]
@@ -469,13 +469,12 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     for (int s = 0; s < 23; s++) B2[s] = a.w2[(4 * s + kq) * 32 + l15];
 #pragma unroll
     for (int r = 0; r < 4; r++) WH[r] = a.wh[(((lane >> 2) & 7) + 8 * r) * 32 + 4 * (lane >> 5) + (lane & 3)];   // heads: see phase 3
-    const int hcell = lane & 31;                                 // == 4 ((lane >> 2) & 7) + (lane & 3)
     // (vectors are zero padded to 128 floats)
     const float bias2 = a.b2[l15], slope2 = a.s2[l15];
-    const float bias3 = a.b3[l31], slope3 = a.s3[l31];
+    if (tid < 32) { T3all[tid] = a.b3[tid]; T3all[32 + tid] = a.s3[tid]; }   // (published by the barrier below)
     const f32x4 biasq = {a.bh[4 * (lane >> 5)], a.bh[4 * (lane >> 5) + 1], a.bh[4 * (lane >> 5) + 2], a.bh[4 * (lane >> 5) + 3]};
     // general instantiation only: the per-channel med3 selector (+inf: max(v, s v), -inf: min(v, s v)); dead code when UNIT
-    const float sel2 = trl_prelu_sel(slope2), sel3 = trl_prelu_sel(slope3);
+    const float sel2 = trl_prelu_sel(slope2);
     const f32x4 bias2v = {bias2, bias2, bias2, bias2};
 
     // LDS beyond the live tiles is read by zero-weight k padding: it must hold finite values
@@ -570,7 +569,6 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             }
         }
     };
-    float* const HS = HSall + wave * 32 * 2;
     // Carry strips <-> tiles, a handful of instructions per tile (VALU beside the MFMAs is paid in matrix throughput): the pooled
     // strip is 20 rows x 40 floats = 10 float4 per row (16 threads per row, 10 active: rows 0..15 in one pass, 16..19 in a second);
     // the conv2 strip is 18 rows x 34 floats = 17 float2 per row (32 threads per row, 17 active: three passes).
@@ -935,21 +933,27 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         tile_nxt = __builtin_amdgcn_readfirstlane(next_tile_s);
         if (tile_nxt < t_end) { nxt = decode(tile_nxt); if (!(dbg_skip & 1)) issue_input(nxt); }
 
-        // ---- phase 3: conv3 + PReLU -> per-wave staging -> heads -> candidates -------------------------------
+        // ---- phase 3: conv3 + PReLU -> heads -> candidates, register to register -------------------------------------
         // the conv2 columns the right neighbour will not recompute (RA is read-only until the barrier that ends the tile)
         if (feeds_next) copy_conv2(std::true_type{});
         if (!(dbg_skip & 8)) {
-            float* ST = RB + wave * 32 * ST_LD;
             const float fscale = g.scale;
-#pragma unroll 1
-            for (int it = 0; it < 2; it++) {
-                const int mt = wave + 4 * it;               // 8 M-tiles of 32 rows = 2 output rows each
-                if (2 * mt >= vrows) continue;              // bottom-edge tile: these two output rows lie below the level
+            const f32x4* T3 = reinterpret_cast<const f32x4*>(T3all);
+            // conv3 runs TRANSPOSED on mfma_f32_32x32x2: the A operand is the weight (rows = output channels), the B operand the
+            // activation (columns = the 32 cells of the M-tile = 2 output rows), the same two LDS words per lane and k-step as the
+            // other way round and the same chain per output (acc = bias, k ascending).  Lane l then holds 16 channels --
+            // 8 (q >> 2) + (q & 3) + 4 hh -- of ONE cell (l & 31): exactly what the heads' B operand wants, so nothing is staged
+            // through LDS between conv3 and the heads (round 3 measured that round trip and the idle chain behind it at 6 % of the
+            // kernel).  `between(sx, u)` is called after MFMA u of sixth sx: the previous M-tile's head chain rides in those slots.
+            auto conv3 = [&](int mt, f32x16& P, auto&& between) __attribute__((always_inline)) {
                 const int y = mt * 2 + (l31 >> 4), x = l31 & 15;
                 const int base = (y * C2_T + x) * C2_LD + hh;
                 f32x16 acc;
 #pragma unroll
-                for (int q = 0; q < 16; q++) acc[q] = bias3;
+                for (int qa = 0; qa < 4; qa++) {
+                    const f32x4 b4 = T3[2 * qa + hh];                       // bias of channels 8 qa + 4 hh .. + 3
+                    acc[4 * qa] = b4[0]; acc[4 * qa + 1] = b4[1]; acc[4 * qa + 2] = b4[2]; acc[4 * qa + 3] = b4[3];
+                }
                 // 6 x 12 k-steps, double buffered: the operands of sixth i+1 are requested before the MFMAs of sixth i
                 // issue, so only the first sixth's LDS latency is exposed.
                 float xa[2][12], wb[2][12];
@@ -962,40 +966,57 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     }
                 };
                 read_sixth(0, xa[0], wb[0]);
-#pragma unroll
-                for (int sx = 0; sx < 6; sx++) {
+                pn_static_for(std::make_integer_sequence<int, 6>{}, [&](auto SX) __attribute__((always_inline)) {
+                    constexpr int sx = decltype(SX)::value;
                     if (sx < 5) read_sixth(sx + 1, xa[(sx + 1) & 1], wb[(sx + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 12; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[sx & 1][u], wb[sx & 1][u], acc, 0, 0, 0);
+                    pn_static_for(std::make_integer_sequence<int, 12>{}, [&](auto UU) __attribute__((always_inline)) {
+                        constexpr int u = decltype(UU)::value;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[sx & 1][u], xa[sx & 1][u], acc, 0, 0, 0);
+                        between(SX, UU);
+                    });
                     __builtin_amdgcn_sched_barrier(0);
-                }
+                });
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-                    ST[row * ST_LD + l31] = prelu_t<UNIT>(acc[q], slope3, sel3);
+                for (int qa = 0; qa < 4; qa++) {
+                    const f32x4 s4 = T3[8 + 2 * qa + hh];                   // PReLU slopes of the same channels
+#pragma unroll
+                    for (int qb = 0; qb < 4; qb++) P[4 * qa + qb] = prelu_t<UNIT>(acc[4 * qa + qb], s4[qb], UNIT ? 0.f : trl_prelu_sel(s4[qb]));
                 }
-                __builtin_amdgcn_wave_barrier();
-                // heads (1x1, 32 -> 2 + 4) on v_mfma_f32_4x4x1_16B_f32: sixteen 4x4 blocks per instruction, ONE k per instruction.
-                // Block b of lanes 4b..4b+3 = cells 4(b & 7) .. +3 (the B operand: the cell's conv3 value at k), outputs
-                // 4(b >> 3) .. +3 (the A operand: weights W[k][4(b >> 3) + i], broadcast inside each group of eight blocks from block
-                // k & 7 of register k >> 3 -- cbsz = 3, abid = k & 7): one instruction does both output groups of all 32 cells,
-                // 32 instructions x 8 cycles = half the issue time of two 16-row 16x16x4 tiles whose N = 6 is padded to 16, and
-                // every lane ends up holding ITS cell's logits (no transposing staging).  Same chain: acc = bias, k ascending.
-                f32x4 hq = biasq;
-#define TRL_HSTEP(k) hq = __builtin_amdgcn_mfma_f32_4x4x1f32(WH[(k) >> 3], ST[hcell * ST_LD + (k)], hq, 3, (k) & 7, 0);
-                TRL_HSTEP(0) TRL_HSTEP(1) TRL_HSTEP(2) TRL_HSTEP(3) TRL_HSTEP(4) TRL_HSTEP(5) TRL_HSTEP(6) TRL_HSTEP(7)
-                TRL_HSTEP(8) TRL_HSTEP(9) TRL_HSTEP(10) TRL_HSTEP(11) TRL_HSTEP(12) TRL_HSTEP(13) TRL_HSTEP(14) TRL_HSTEP(15)
-                TRL_HSTEP(16) TRL_HSTEP(17) TRL_HSTEP(18) TRL_HSTEP(19) TRL_HSTEP(20) TRL_HSTEP(21) TRL_HSTEP(22) TRL_HSTEP(23)
-                TRL_HSTEP(24) TRL_HSTEP(25) TRL_HSTEP(26) TRL_HSTEP(27) TRL_HSTEP(28) TRL_HSTEP(29) TRL_HSTEP(30) TRL_HSTEP(31)
-#undef TRL_HSTEP
-                // lanes 0..31: {logit0, logit1, reg0, reg1} of cell = lane; lanes 32..63: {reg2, reg3, -, -} of cell = lane - 32
-                if (lane >= 32) { HS[2 * hcell] = hq[0]; HS[2 * hcell + 1] = hq[1]; }
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 32) {                            // one lane per cell of the 32-row tile
+            };
+            // heads (1x1, 32 -> 2 + 4) on v_mfma_f32_4x4x1_16B_f32: sixteen 4x4 blocks per instruction, ONE k per instruction.
+            // Block b of lanes 4b..4b+3 = cells 4(b & 7) .. +3 (the B operand: the cell's conv3 value at k), outputs
+            // 4(b >> 3) .. +3 (the A operand: weights W[k][4(b >> 3) + i], broadcast inside each group of eight blocks from block
+            // k & 7 of register k >> 3 -- cbsz = 3, abid = k & 7): one instruction does both output groups of all 32 cells and
+            // every lane ends up holding ITS cell's logits.  Same chain: acc = bias, k ascending.  Channel k of cell c sits in
+            // lane c + 32 ((k >> 2) & 1), register 4 (k >> 3) + (k & 3): one v_permlane32_swap of the register with a copy of
+            // itself yields the lower half's value in every lane (k & 4 == 0) and the upper half's (k & 4 == 4).
+            unsigned hlo[4], hhi[4];
+            auto head_step = [&](auto H_T, const f32x16& P, f32x4& hq) __attribute__((always_inline)) {
+                constexpr int k = decltype(H_T)::value, ga = k >> 3, gb = k & 7;
+                if constexpr (gb == 0) {
+#pragma unroll
+                    for (int qb = 0; qb < 4; qb++) {
+                        const unsigned v = __float_as_uint(P[4 * ga + qb]);
+                        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+                        hlo[qb] = r[0]; hhi[qb] = r[1];
+                    }
+                }
+                const float bk = __uint_as_float(gb < 4 ? hlo[gb & 3] : hhi[gb & 3]);
+                hq = __builtin_amdgcn_mfma_f32_4x4x1f32(WH[ga], bk, hq, 3, gb, 0);
+            };
+            auto heads_all = [&](const f32x16& P, f32x4& hq) __attribute__((always_inline)) {
+                pn_static_for(std::make_integer_sequence<int, 32>{}, [&](auto H_T) __attribute__((always_inline)) { head_step(H_T, P, hq); });
+            };
+            // lanes 0..31: {logit0, logit1, reg0, reg1} of cell = lane; lanes 32..63: {reg2, reg3, -, -} of cell = lane - 32
+            // (the softmax is computed by every lane, branch-free -- lanes 32..63 on their two box offsets, finite and unused -- so
+            // that it can be scheduled into the gaps of a dependent head chain)
+            auto emit = [&](int mt, const f32x4& hq, float p) __attribute__((always_inline)) {
+                const auto u2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(hq[0]), __float_as_uint(hq[0]), false, false);
+                const auto u3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(hq[1]), __float_as_uint(hq[1]), false, false);
+                if (lane < 32) {                                // one lane per cell of the 32-row tile
                     const int oy = ty * TS + mt * 2 + (lane >> 4), ox = tx * TS + (lane & 15);
                     if (oy < g.oh && ox < g.ow) {
-                        const float p = trl_softmax2_p1(hq[0], hq[1]);
                         if (p >= a.thr && !(dbg_skip & 32)) {      // (bit 32: timing-only ablations emit no candidates)
                             const int seg = f * a.L + l;
                             const int sl = atomicAdd(&a.lvl_cnt[seg], 1);
@@ -1006,7 +1027,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                                 c.x2 = floorf((2.f * (float)ox + 12.f) / fscale);
                                 c.y2 = floorf((2.f * (float)oy + 12.f) / fscale);
                                 c.score = p;
-                                c.r0 = hq[2]; c.r1 = hq[3]; c.r2 = HS[2 * lane]; c.r3 = HS[2 * lane + 1];
+                                c.r0 = hq[2]; c.r1 = hq[3]; c.r2 = __uint_as_float(u2[1]); c.r3 = __uint_as_float(u3[1]);
                                 c.cell = oy * g.ow + ox;
                                 a.lvl_rec[(size_t)seg * a.cap + sl] = c;
                             } else {
@@ -1015,7 +1036,41 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                         }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+            };
+            // 8 M-tiles of 32 cells = 2 output rows each; wave w takes M-tiles w and w + 4 (a bottom-edge tile may have neither or
+            // only the first: those output rows lie below the level).  The head chain of the first rides in the MFMA stream of the
+            // second -- one 8-cycle block instruction after every second 64-cycle one, so its 32 dependent steps never wait.
+            const int mt0 = wave, mt1 = wave + 4;
+            if (2 * mt0 < vrows) {
+                f32x16 P0;
+                f32x4 hq0 = biasq;
+                conv3(mt0, P0, [](auto, auto) {});
+                if (2 * mt1 < vrows) {
+                    f32x16 P1;
+                    f32x4 hq1 = biasq;
+                    conv3(mt1, P1, [&](auto SX, auto UU) __attribute__((always_inline)) {
+                        constexpr int sx = decltype(SX)::value, u = decltype(UU)::value, h = sx * 6 + (u >> 1);
+                        if constexpr ((u & 1) == 1 && h < 32) {          // (pinned: the scheduler would bunch the block instructions)
+                            __builtin_amdgcn_sched_barrier(0);
+                            head_step(std::integral_constant<int, h>{}, P0, hq0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                    // ... and the second's chain has the first's softmax (VALU) in its dependency gaps
+                    float p0 = trl_softmax2_p1(hq0[0], hq0[1]);
+                    heads_all(P1, hq1);
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two VALU
+                    }
+                    asm volatile("" : "+v"(p0));                             // (computed HERE, not sunk into the rare branch that reads it)
+                    emit(mt0, hq0, p0);
+                    emit(mt1, hq1, trl_softmax2_p1(hq1[0], hq1[1]));
+                } else {
+                    heads_all(P0, hq0);
+                    emit(mt0, hq0, trl_softmax2_p1(hq0[0], hq0[1]));
+                }
             }
         }
         __syncthreads();   // RA / RB are rewritten by the next tile
