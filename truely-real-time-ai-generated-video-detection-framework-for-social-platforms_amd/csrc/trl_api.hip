@@ -47,7 +47,7 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
     trl_ctx* c = new trl_ctx();
     c->cfg = *cfg;
     // diagnostic only: the clocked PNet instantiation (device-wall-clock span of the launch) runs when TRL_PNET_CLOCK is set
-    if (getenv("TRL_PNET_CLOCK") && hipMalloc((void**)&c->pnet_clk, 16) != hipSuccess) c->pnet_clk = nullptr;
+    if (getenv("TRL_PNET_CLOCK") && (hipMalloc((void**)&c->pnet_clk, 8 * 40) != hipSuccess || hipMemset(c->pnet_clk, 0, 8 * 40) != hipSuccess)) c->pnet_clk = nullptr;
     if (hipMalloc((void**)&c->pnet_cursor, 64) != hipSuccess || hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess ||
         hipEventCreate(&c->ev_call0) != hipSuccess || hipEventCreate(&c->ev_call1) != hipSuccess) {
         trl_set_error("context allocation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -69,7 +69,18 @@ int trl_destroy(trl_ctx* c) {
     if (c->scratch.base) (void)hipFree(c->scratch.base);
     if (c->sims_tmp.base) (void)hipFree(c->sims_tmp.base);
     if (c->pyr_tab) (void)hipFree(c->pyr_tab);
-    if (c->pnet_clk) (void)hipFree(c->pnet_clk);
+    if (c->pnet_clk) {
+        // TRL_PNET_CLOCK: where the waves of the fused PNet launches spent their time (shader clocks per tile and wave, DBG instantiation)
+        unsigned long long t[40];
+        if (hipMemcpy(t, c->pnet_clk, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[2 + 32] > 0) {
+            static const char* nm[8] = {"phase0", "barrier0", "phase1", "barrier1", "phase2", "barrier2", "phase3", "barrier3"};
+            const double tiles = (double)t[2 + 32];
+            fprintf(stderr, "[TRL_PNET_CLOCK] shader clocks per tile (wave 0..3), %.0f workgroup-tiles\n", tiles);
+            for (int k = 0; k < 8; k++)
+                fprintf(stderr, "[TRL_PNET_CLOCK] %-9s %8.0f %8.0f %8.0f %8.0f\n", nm[k], t[2 + k] / tiles, t[2 + 8 + k] / tiles, t[2 + 16 + k] / tiles, t[2 + 24 + k] / tiles);
+        }
+        (void)hipFree(c->pnet_clk);
+    }
     if (c->pnet_cursor) (void)hipFree(c->pnet_cursor);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->ev_call0) (void)hipEventDestroy(c->ev_call0);

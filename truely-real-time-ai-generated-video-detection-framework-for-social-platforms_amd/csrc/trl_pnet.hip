@@ -524,17 +524,24 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         if (n - q * d >= d) q++;
         return q;
     };
-    struct TileId { int f, l, ty, tx; };
+    // A decoded tile carries the fields of its level that the loop reads: they are fetched HERE (scalar loads from the argument
+    // block, issued while the previous tile is in phase 3), not at the top of the tile's own iteration -- left to itself hipcc
+    // indexed a.lv[] with a VGPR and put a vector-memory round trip (~1,100 clocks per tile, measured with TRL_PNET_CLOCK) in
+    // front of phase 0.
+    struct TileId { int f, l, ty, tx, h, w, oh, ow, tiles_x, pix0; float scale; };
     auto decode = [&](int tile) {
         TileId t;
         t.f = sdiv(tile, a.tpf_magic, a.tiles_per_frame);
         const int tt = tile - t.f * a.tiles_per_frame;
-        t.l = 0;
+        int lv = 0;
 #pragma unroll
-        for (int i = 1; i < 16; i++) t.l += (tt >= lvl_t0[i]) ? 1 : 0;
-        const int tq = tt - a.lv[t.l].tile0;
-        t.ty = sdiv(tq, a.lv[t.l].txmagic, a.lv[t.l].tiles_x);
-        t.tx = tq - t.ty * a.lv[t.l].tiles_x;
+        for (int i = 1; i < 16; i++) lv += (tt >= lvl_t0[i]) ? 1 : 0;
+        t.l = __builtin_amdgcn_readfirstlane(lv);
+        const PLevel& g = a.lv[t.l];
+        t.h = g.h; t.w = g.w; t.oh = g.oh; t.ow = g.ow; t.tiles_x = g.tiles_x; t.pix0 = g.pix0; t.scale = g.scale;
+        const int tq = tt - g.tile0;
+        t.ty = sdiv(tq, g.txmagic, t.tiles_x);
+        t.tx = tq - t.ty * t.tiles_x;
         return t;
     };
     // The next tile's 42x42 input pixels are fetched into registers while the current tile is in phase 3
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     const int pin_iy0 = tid / IN_T, pin_ix0 = tid - pin_iy0 * IN_T;
     float4 pre[7];
     auto issue_input = [&](const TileId& t) {
-        const PLevel& g = a.lv[t.l];
+        const TileId& g = t;
         const int gy0 = t.ty * 2 * TS, gx0 = t.tx * 2 * TS;
         const char* srcb = reinterpret_cast<const char*>(a.pyr + (long long)t.f * a.pyr_stride + g.pix0 + (long long)gy0 * g.w + gx0);
         const int w16 = g.w * 12;                  // bytes per pyramid row (12 B pixels)
@@ -614,9 +621,16 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     int rot = 0, tile_nxt = tile, run_pos = 0;
     bool follows = false;                   // this tile is the right neighbour of the one this workgroup has just finished, which left its strips
     bool fed = false;
+    // DBG + TRL_PNET_CLOCK: shader-clock time of every wave in each phase and at each barrier, summed over the launch (clk[2 + 8 wave + k])
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = 0;
+    const bool prof = DBG && a.clk != nullptr;
+    auto stamp = [&](int k) {
+        if (DBG && prof) { const unsigned long long t = clock64(); pt[k] += t - pt_last; pt_last = t; }
+    };
+    if (DBG && prof) pt_last = clock64();
     for (; tile < t_end; follows = fed && (tile_nxt == tile + 1), tile = tile_nxt, cur = nxt, rot++) {
         const int f = cur.f, l = cur.l, ty = cur.ty, tx = cur.tx;
-        const PLevel& g = a.lv[l];
+        const TileId& g = cur;
         const int vrows = (g.oh - ty * TS < TS) ? g.oh - ty * TS : TS;      // valid output rows of this tile
         const bool carry = follows && tx > 0;                                // consecutive tile index and not a row start: same frame, level, row
         const bool last_of_run = run_pos + 1 >= run_len;
@@ -632,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         run_len = last_of_run ? next_len : run_len;
 
         // ---- phase 0: prefetched input tile -> RA as [42][42][3] ---------------------------------------------
+        stamp(7);
         if (!(dbg_skip & 16)) {
 #pragma unroll
         for (int i = 0; i < 7; i++) {        // p < 1792: the 28 pixels past the tile land in RA's tail (finite, never a live operand)
@@ -639,7 +654,9 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             d[0] = pre[i].x; d[1] = pre[i].y; d[2] = pre[i].z;
         }
         }
+        stamp(0);
         __syncthreads();
+        stamp(1);
 
         // ---- phase 1: conv1 + 2x2 ceil max-pool + PReLU -> RB as [20][20][10] ------------------------------
         // conv1 (3 -> 10 channels, K = 27) runs on the 4x4x1 block instruction (see mfma4 above): wave w owns pooled rows w, w+4,
@@ -812,7 +829,9 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 else { if (two) x_units(std::true_type{}, std::true_type{}, A, B); else x_units(std::true_type{}, std::false_type{}, A, B); }
             }
         }
+        stamp(2);
         __syncthreads();
+        stamp(3);
 
         // ---- phase 2: conv2 + PReLU -> RA as [324][17] ---------------------------------------------------------
         if (!(dbg_skip & 4)) {
@@ -927,7 +946,9 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             }   // !carry
         }
         if (tid == 0) next_tile_s = t_begin + cursor;   // the cursor's atomic has had phases 0-2 to return
+        stamp(4);
         __syncthreads();
+        stamp(5);
 
         // next tile's input: global loads into registers only (RA is still read by phase 3)
         tile_nxt = __builtin_amdgcn_readfirstlane(next_tile_s);
@@ -1073,7 +1094,14 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 }
             }
         }
+        stamp(6);
         __syncthreads();   // RA / RB are rewritten by the next tile
+        stamp(7);
+    }
+    if (DBG && prof && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) atomicAdd(&a.clk[2 + 8 * wave + k], pt[k]);
+        if (wave == 0) atomicAdd(&a.clk[2 + 32], (unsigned long long)rot);
     }
     if (DBG && a.clk && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
