@@ -41,9 +41,8 @@ constexpr int IN_T = 2 * TS + 10; // 42 input pixels
 constexpr int P1_T = TS + 4;      // 20 pooled cells
 constexpr int C2_T = TS + 2;      // 18 conv2 cells
 constexpr int C2_LD = 17;         // padded channel stride of the conv2 tile (bank spread for conv3 reads)
-constexpr int ST_LD = 33;         // padded channel stride of the per-wave conv3 staging tile
 constexpr int REGION_A = C2_T * C2_T * C2_LD;        // 5508 floats: input tile, later conv2 output
-constexpr int REGION_B = 4 * 32 * ST_LD;             // 4224 floats: pooled conv1, later conv3 staging
+constexpr int REGION_B = P1_T * P1_T * 10 + 224;     // 4000 floats of pooled conv1 + the reach of conv2's zero-weight k padding (k = 90, 91 of the last cells: finite, zeroed once)
 static_assert(3 * 7 * 256 <= REGION_A, "input tile (+ the 28 overhang pixels of the 7x256 copy) fits region A");
 static_assert(P1_T * P1_T * 10 <= REGION_B, "pooled tile fits region B");
 // Horizontal carry between consecutive tiles of a tile row (a workgroup takes RUNS of consecutive tiles): the right-most 4 pooled
@@ -53,7 +52,15 @@ static_assert(P1_T * P1_T * 10 <= REGION_B, "pooled tile fits region B");
 // (18 instead of 21 M-tiles).  Same values: every cell is the same fmaf chain over the same pixels whichever tile computes it.
 constexpr int CARRY_P = P1_T * 4 * 10;               // 800 floats: pooled rows x 4 columns x 10 channels
 constexpr int CARRY_C = C2_T * 2 * C2_LD;            // 612 floats: conv2 rows x 2 columns x 17 (padded channels)
-constexpr int DYN_LDS = (144 * 32 + CARRY_P + CARRY_C) * 4;   // conv3 weights + the two carry strips (dynamic: static LDS is capped at 64 KB)
+// Vertical carry (round 3): the tiles of a level are walked in BANDS of BAND tile rows, column by column (top tile, the tile below
+// it, then the next column), so the tile below follows its upper neighbour in the same workgroup: ITS first 4 pooled rows and
+// 2 conv2 rows are the upper tile's last ones.  A tile with both carries computes 16 x 16 new pooled cells (one super unit per
+// wave and nothing else) and 16 x 16 new conv2 cells (16 M-tiles, four per wave).  The horizontal strips need one slot per band row.
+constexpr int BAND = 2;
+constexpr int VCARRY_P = 4 * P1_T * 10;              // 800 floats: 4 pooled rows x 20 columns x 10 channels (contiguous in the tile)
+constexpr int VCARRY_C = 2 * C2_T * C2_LD;           // 612 floats: 2 conv2 rows x 18 columns x 17
+constexpr int DYN_LDS = (144 * 32 + BAND * (CARRY_P + CARRY_C) + VCARRY_P + VCARRY_C) * 4;   // conv3 weights + the carry strips (dynamic: static LDS is capped at 64 KB)
+static_assert((144 * 32) % 4 == 0 && CARRY_P % 4 == 0 && CARRY_C % 4 == 0 && VCARRY_P % 4 == 0, "strips stay 16-byte aligned");
 
 // One pyramid pixel = three floats (a fourth padding float would be 25 % of the pyramid's write + read traffic).
 struct PyrPx { float b, g, r; };
@@ -62,6 +69,8 @@ typedef float f32x3_nt __attribute__((ext_vector_type(3), aligned(4)));
 struct PLevel {
     int h, w, oh, ow;        // level size, PNet map size
     int tiles_x, tile0;      // tiles per row, first tile index of the level inside a frame
+    int tiles_y;             // tile rows
+    unsigned bmagic;         // ceil(2^32 / (BAND * tiles_x)): band of a tile index
     int pix0;                // pixel offset of the level inside a frame's pyramid
     int pix_pad;             // h*w rounded up to 64 (pyramid slots of the level)
     int gshift, work0;       // pyramid kernel: log2(lanes per pixel), first thread of the level inside a frame
@@ -449,11 +458,12 @@ template <bool UNIT, bool NEG1, bool DBG>
 __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
     __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
-    __shared__ __attribute__((aligned(16))) float T3all[64];      // conv3 bias[32], PReLU slopes[32]: a lane's 16 channels differ per register (phase 3)
+    __shared__ __attribute__((aligned(16))) float T3all[72];      // conv3 bias[32], PReLU slopes[32] (a lane's 16 channels differ per register), head bias[8] (phase 3)
     extern __shared__ __attribute__((aligned(16))) float DYN[];  // DYN_LDS bytes, then whatever a tuning run pads (TRL_PNET_XLDS)
     float* const B3S = DYN;                                       // conv3 weights [k][cout]: read per k-chain batch, not held in VGPRs
-    float* const CP = DYN + 144 * 32;                             // carried pooled columns [20][4][10]
-    float* const CC = CP + CARRY_P;                               // carried conv2 columns  [18][2][17]
+    float* const CP0 = DYN + 144 * 32;                            // per band row: carried pooled columns [20][4][10], conv2 columns [18][2][17]
+    float* const VP = CP0 + BAND * (CARRY_P + CARRY_C);           // carried pooled rows [4][20][10]
+    float* const VC = VP + VCARRY_P;                              // carried conv2 rows  [2][18][17]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every M-tile index below is SALU work
@@ -471,8 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     for (int r = 0; r < 4; r++) WH[r] = a.wh[(((lane >> 2) & 7) + 8 * r) * 32 + 4 * (lane >> 5) + (lane & 3)];   // heads: see phase 3
     // (vectors are zero padded to 128 floats)
     const float bias2 = a.b2[l15], slope2 = a.s2[l15];
-    if (tid < 32) { T3all[tid] = a.b3[tid]; T3all[32 + tid] = a.s3[tid]; }   // (published by the barrier below)
-    const f32x4 biasq = {a.bh[4 * (lane >> 5)], a.bh[4 * (lane >> 5) + 1], a.bh[4 * (lane >> 5) + 2], a.bh[4 * (lane >> 5) + 3]};
+    if (tid < 32) { T3all[tid] = a.b3[tid]; T3all[32 + tid] = a.s3[tid]; if (tid < 8) T3all[64 + tid] = a.bh[tid]; }   // (published by the barrier below)
     // general instantiation only: the per-channel med3 selector (+inf: max(v, s v), -inf: min(v, s v)); dead code when UNIT
     const float sel2 = trl_prelu_sel(slope2);
     const f32x4 bias2v = {bias2, bias2, bias2, bias2};
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     // block, issued while the previous tile is in phase 3), not at the top of the tile's own iteration -- left to itself hipcc
     // indexed a.lv[] with a VGPR and put a vector-memory round trip (~1,100 clocks per tile, measured with TRL_PNET_CLOCK) in
     // front of phase 0.
-    struct TileId { int f, l, ty, tx, h, w, oh, ow, tiles_x, pix0; float scale; };
+    struct TileId { int f, l, ty, tx, h, w, oh, ow, tiles_x, pix0, rib, rows; float scale; };   // rib: row inside the band, rows: tile rows of the band
     auto decode = [&](int tile) {
         TileId t;
         t.f = sdiv(tile, a.tpf_magic, a.tiles_per_frame);
@@ -539,9 +548,15 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         t.l = __builtin_amdgcn_readfirstlane(lv);
         const PLevel& g = a.lv[t.l];
         t.h = g.h; t.w = g.w; t.oh = g.oh; t.ow = g.ow; t.tiles_x = g.tiles_x; t.pix0 = g.pix0; t.scale = g.scale;
+        // band order: index inside the level -> (band, column, row inside the band); the last band of a level may be one row high
         const int tq = tt - g.tile0;
-        t.ty = sdiv(tq, g.txmagic, t.tiles_x);
-        t.tx = tq - t.ty * t.tiles_x;
+        const int band = sdiv(tq, g.bmagic, BAND * t.tiles_x);
+        const int rb = tq - band * (BAND * t.tiles_x);
+        t.rows = g.tiles_y - BAND * band < BAND ? g.tiles_y - BAND * band : BAND;
+        static_assert(BAND == 2, "column of a band position: a shift");
+        t.tx = t.rows == 2 ? rb >> 1 : rb;
+        t.rib = rb - t.tx * t.rows;
+        t.ty = BAND * band + t.rib;
         return t;
     };
     // The next tile's 42x42 input pixels are fetched into registers while the current tile is in phase 3
@@ -578,32 +593,56 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     };
     // Carry strips <-> tiles, a handful of instructions per tile (VALU beside the MFMAs is paid in matrix throughput): the pooled
     // strip is 20 rows x 40 floats = 10 float4 per row (16 threads per row, 10 active: rows 0..15 in one pass, 16..19 in a second);
-    // the conv2 strip is 18 rows x 34 floats = 17 float2 per row (32 threads per row, 17 active: three passes).
+    // the conv2 strip is 18 rows x 34 floats = 17 float2 per row (32 threads per row, 17 active: three passes).  (Splitting the
+    // copies -- reads at the top of a phase, writes at its end -- hides their LDS round trips but holds ~20 registers across the
+    // phases: the kernel then spills ~25 lane constants to scratch and loses 5 %: measured, reverted.)
     typedef float f32x2c __attribute__((ext_vector_type(2)));
-    auto copy_pooled = [&](auto SAVE_T) {
+    // (the copies index with `ctid`, the thread index laundered once per tile: their ~12 lane addresses are then recomputed, one VALU
+    // each, instead of hoisted out of the tile loop and -- at 256 VGPRs -- spilled; a scratch reload waits on vmcnt(0), i.e. on
+    // the next tile's input loads that are in flight for exactly that reason)
+    int ctid = tid;
+    auto copy_pooled = [&](auto SAVE_T, float* CP) {
         constexpr bool SAVE = decltype(SAVE_T)::value;          // tile -> strip (columns 16..19), or strip -> tile (columns 0..3)
-        const int q = tid & 15;
+        const int q = ctid & 15;
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
-            const int r = (tid >> 4) + 16 * pass;
-            if (q < 10 && (pass == 0 || tid < 64)) {
+            const int r = (ctid >> 4) + 16 * pass;
+            if (q < 10 && (pass == 0 || ctid < 64)) {
                 f32x4* t = reinterpret_cast<f32x4*>(RB + r * (P1_T * 10) + (SAVE ? 16 * 10 : 0) + 4 * q);
                 f32x4* c = reinterpret_cast<f32x4*>(CP + r * 40 + 4 * q);
                 if (SAVE) *c = *t; else *t = *c;
             }
         }
     };
-    auto copy_conv2 = [&](auto SAVE_T) {
+    auto copy_conv2 = [&](auto SAVE_T, float* CC) {
         constexpr bool SAVE = decltype(SAVE_T)::value;          // columns 16..17 -> strip, or strip -> columns 0..1
-        const int q = tid & 31;
+        const int q = ctid & 31;
 #pragma unroll
         for (int pass = 0; pass < 3; pass++) {
-            const int r = (tid >> 5) + 8 * pass;
-            if (q < 17 && (pass < 2 || tid < 64)) {
+            const int r = (ctid >> 5) + 8 * pass;
+            if (q < 17 && (pass < 2 || ctid < 64)) {
                 f32x2c* t = reinterpret_cast<f32x2c*>(RA + r * (C2_T * C2_LD) + (SAVE ? 16 * C2_LD : 0) + 2 * q);
                 f32x2c* c = reinterpret_cast<f32x2c*>(CC + r * 34 + 2 * q);
                 if (SAVE) *c = *t; else *t = *c;
             }
+        }
+    };
+    // vertical strips: contiguous in both tiles (whole rows), one float4 per thread
+    auto copy_rows = [&](auto SAVE_T) {                          // pooled rows 16..19 -> VP, or VP -> rows 0..3 (RB)
+        constexpr bool SAVE = decltype(SAVE_T)::value;
+        if (ctid < VCARRY_P / 4) {
+            f32x4* t = reinterpret_cast<f32x4*>(RB + (SAVE ? 16 * P1_T * 10 : 0)) + ctid;
+            f32x4* c = reinterpret_cast<f32x4*>(VP) + ctid;
+            if (SAVE) *c = *t; else *t = *c;
+        }
+    };
+    auto copy_rows2 = [&](auto SAVE_T) {                         // conv2 rows 16..17 -> VC, or VC -> rows 0..1 (RA)
+        constexpr bool SAVE = decltype(SAVE_T)::value;
+        static_assert((16 * C2_T * C2_LD) % 4 == 0 && VCARRY_C % 4 == 0, "float4 copies");
+        if (ctid < VCARRY_C / 4) {
+            f32x4* t = reinterpret_cast<f32x4*>(RA + (SAVE ? 16 * C2_T * C2_LD : 0)) + ctid;
+            f32x4* c = reinterpret_cast<f32x4*>(VC) + ctid;
+            if (SAVE) *c = *t; else *t = *c;
         }
     };
     // Dynamic schedule inside the XCD's chunk: a workgroup takes the next RUN of a.run consecutive tiles of its XCD from an atomic
@@ -619,8 +658,11 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     TileId cur = decode(tile < t_end ? tile : 0), nxt = cur;
     if (tile < t_end) issue_input(cur);
     int rot = 0, tile_nxt = tile, run_pos = 0;
-    bool follows = false;                   // this tile is the right neighbour of the one this workgroup has just finished, which left its strips
-    bool fed = false;
+    // who left the strips: tile index of the last saver of each horizontal slot and of the vertical strips (a tile carries only
+    // from exactly its neighbour's index, so a stale entry can never match)
+    int hs_tile[BAND], vs_tile = -1;
+#pragma unroll
+    for (int i = 0; i < BAND; i++) hs_tile[i] = -1;
     // DBG + TRL_PNET_CLOCK: shader-clock time of every wave in each phase and at each barrier, summed over the launch (clk[2 + 8 wave + k])
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = 0;
     const bool prof = DBG && a.clk != nullptr;
@@ -628,14 +670,21 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         if (DBG && prof) { const unsigned long long t = clock64(); pt[k] += t - pt_last; pt_last = t; }
     };
     if (DBG && prof) pt_last = clock64();
-    for (; tile < t_end; follows = fed && (tile_nxt == tile + 1), tile = tile_nxt, cur = nxt, rot++) {
+    for (; tile < t_end; tile = tile_nxt, cur = nxt, rot++) {
         const int f = cur.f, l = cur.l, ty = cur.ty, tx = cur.tx;
         const TileId& g = cur;
+        asm volatile("" : "+v"(ctid));
         const int vrows = (g.oh - ty * TS < TS) ? g.oh - ty * TS : TS;      // valid output rows of this tile
-        const bool carry = follows && tx > 0;                                // consecutive tile index and not a row start: same frame, level, row
+        // left neighbour = `rows` positions back in the band order, upper neighbour = the previous position
+        const bool carry = tx > 0 && (g.rib == 0 ? hs_tile[0] : hs_tile[1]) == tile - g.rows;
+        const bool vcarry = g.rib > 0 && vs_tile == tile - 1;
         const bool last_of_run = run_pos + 1 >= run_len;
-        const bool feeds_next = !last_of_run && tx + 1 < g.tiles_x;        // the next tile of the run is this tile's right neighbour
-        fed = feeds_next;
+        const bool feeds_next = run_pos + g.rows < run_len && tx + 1 < g.tiles_x;   // the right neighbour is a later tile of this run
+        const bool feeds_down = !last_of_run && g.rib + 1 < g.rows;                   // the next tile of the run is the tile below
+        float* const CP = CP0 + g.rib * (CARRY_P + CARRY_C);
+        float* const CC = CP + CARRY_P;
+        if (feeds_next) { if (g.rib == 0) hs_tile[0] = tile; else hs_tile[1] = tile; }
+        if (feeds_down) vs_tile = tile;
         int cursor = tile + 1 - t_begin;
         // Guided self-scheduling: near the end of the XCD's chunk the runs shrink (down to single tiles), so the workgroups of an XCD
         // finish within a tile of each other instead of within a run.  Any run length is correct: a run is whatever atomicAdd hands out.
@@ -674,7 +723,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             const bool fast = vy >= 2 * P1_T && vx >= 2 * P1_T;
             // CARRY: pooled columns 0..3 come from the left neighbour (CP, written in its phase 2): only column groups pg = 1..4 are
             // computed -- 20 M-tiles per wave instead of 25
-            if (carry) copy_pooled(std::false_type{});
+            if (carry) copy_pooled(std::false_type{}, CP);
+            if (vcarry) copy_rows(std::false_type{});      // (rows 0..3 of the strip columns arrive twice, with the same values)
             // Units of this wave: the wide units (columns 4..19) of its five pooled rows wave + 4 i; a tile that does not carry also
             // computes columns 0..3 as five NARROW units (4 rows x 4 columns each): narrow unit `wave` goes to this wave, narrow unit 4
             // to one wave in turn.  Units run in pairs (six independent accumulator chains keep the 8-cycle instruction issuing back to
@@ -762,11 +812,12 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             auto x_super = [&](auto EDGE_T) {
                 constexpr bool EDGE = decltype(EDGE_T)::value;
                 const float ninf = -__builtin_inff();
-                const int srow = wave + 4 * xj, scol = 4 + xb;
+                const int srow = wave + 4 * xj + (vcarry ? 4 : 0), scol = 4 + xb;   // a vertically carried tile computes rows 4..19
+                const int sv_l = vcarry ? 8 * IN_T * 3 : 0, sv_s = vcarry ? 4 * P1_T * 10 : 0;
                 f32x4 mx[3], mn[3];
                 pn_static_for(std::make_integer_sequence<int, 2>{}, [&](auto PP) __attribute__((always_inline)) {
                     constexpr int pp = decltype(PP)::value;      // passes 2 pp (dx = 0) and 2 pp + 1 (dx = 1) of conv1 row parity dy = pp
-                    const int lbA = c1s_l + pp * (IN_T * 3), lbB = lbA + 3;
+                    const int lbA = c1s_l + sv_l + pp * (IN_T * 3), lbB = lbA + 3;
                     f32x4 accA[3], accB[3];
                     float xa[2][9], xc[2][9];
                     auto rd = [&](int t, float* xo, int lb) {
@@ -814,17 +865,20 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     if (EDGE) o[c] = cv ? o[c] : 0.f;
                 }
 #pragma unroll
-                for (int c = 0; c < 10; c += 2) *reinterpret_cast<f32x2c*>(RB + c1s_s + c) = f32x2c{o[c], o[c + 1]};
+                for (int c = 0; c < 10; c += 2) *reinterpret_cast<f32x2c*>(RB + c1s_s + sv_s + c) = f32x2c{o[c], o[c + 1]};
             };
             if (fast) x_super(std::false_type{}); else x_super(std::true_type{});
-            // ... the fifth row (wave + 16) and, in a tile that does not carry, the narrow units as quad units (pool = the block's lanes)
+            // ... the fifth row (wave + 16) and, in a tile that does not carry, the narrow units as quad units (pool = the block's lanes).
+            // A vertically carried tile has no fifth row (rows 4..19 are the super unit); without a left neighbour its columns 0..3 of
+            // rows 4..19 are narrow units 1..4, one per wave; with both carries there is nothing left.
             const int extra_wave = rot & 3;                      // the wave that takes narrow unit 4 of a tile that does not carry
 #pragma unroll 1
             for (int pr = 2; pr < 4; pr++) {
+                if (vcarry && (carry || pr == 3)) break;
                 if (pr == 3 && (carry || wave != extra_wave)) break;
-                const XU A = pr < 3 ? wide_u(4) : narrow_u(4);
+                const XU A = vcarry ? narrow_u(wave + 1) : (pr < 3 ? wide_u(4) : narrow_u(4));
                 const XU B = narrow_u(wave);
-                const bool two = pr == 2 && !carry;
+                const bool two = pr == 2 && !carry && !vcarry;
                 if (fast) { if (two) x_units(std::false_type{}, std::true_type{}, A, B); else x_units(std::false_type{}, std::false_type{}, A, B); }
                 else { if (two) x_units(std::true_type{}, std::true_type{}, A, B); else x_units(std::true_type{}, std::false_type{}, A, B); }
             }
@@ -845,16 +899,19 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             const int lim2 = C2_T * (vrows + 3 < C2_T ? vrows + 3 : C2_T);   // conv2 cells conv3 reads: rows 0 .. vrows+2
             // the pooled columns the right neighbour will not recompute (RB is read-only during this phase; CP was consumed
             // before the barrier that ended phase 1)
-            if (feeds_next) copy_pooled(std::true_type{});
+            if (feeds_next) copy_pooled(std::true_type{}, CP);
+            if (feeds_down) copy_rows(std::true_type{});
+            if (vcarry) copy_rows2(std::false_type{});       // conv2 rows 0..1 come from the upper neighbour (VC, written in its phase 3)
+            if (carry) copy_conv2(std::false_type{}, CC);    // conv2 columns 0..1 from the left neighbour (CC, written in its phase 3)
+            const int r0 = vcarry ? 2 : 0;                      // first conv2 row this tile computes
             float xa[23], xb[23];
             if (carry) {
                 // conv2 columns 0..1 come from the left neighbour (CC, written in its phase 3); the 16 new columns of row y are
                 // ONE M-tile: 18 M-tiles (instead of 21), wave role w2 takes rows w2, w2+4, .., every address a lane base + immediate
-                copy_conv2(std::false_type{});
                 const int rows2 = vrows + 3 < C2_T ? vrows + 3 : C2_T;          // conv2 rows conv3 reads
                 const int cbase = (2 + l15) * 10;
                 auto read_rows = [&](int j) {
-                    int yA = w2 + 8 * j;
+                    int yA = r0 + w2 + 8 * j;
                     yA = yA < C2_T ? yA : C2_T - 1;                         // (rows past the tile are not computed: stay inside it)
                     const int yB = (yA + 4 < C2_T) ? yA + 4 : yA;
 #pragma unroll
@@ -867,7 +924,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 read_rows(0);
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    const int yA = w2 + 8 * j, yB = yA + 4;
+                    const int yA = r0 + w2 + 8 * j, yB = yA + 4;
                     const bool hasA = yA < rows2, hasB = yB < rows2;         // (rows2 <= 18: also bounds the row index)
                     f32x4 accA = bias2v, accB = bias2v;
                     __builtin_amdgcn_sched_barrier(0);
@@ -895,10 +952,12 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     }
                 }
             } else {
+            // (a vertically carried tile without a left neighbour: rows 2..17 = cells 36..323 = 18 M-tiles, the same walk shifted)
+            const int c0 = r0 * C2_T, nmt2 = vcarry ? 18 : 21;
             auto read_pair2 = [&](int j) {
                 const int mtA = w2 + 8 * j, mtB = (mtA + 4 < 21) ? mtA + 4 : mtA;
-                int mA = mtA * 16 + l15; mA = mA < 324 ? mA : 323;
-                int mB = mtB * 16 + l15; mB = mB < 324 ? mB : 323;
+                int mA = c0 + mtA * 16 + l15; mA = mA < 324 ? mA : 323;
+                int mB = c0 + mtB * 16 + l15; mB = mB < 324 ? mB : 323;
                 const int yA = mA / C2_T, xA = mA - yA * C2_T, yB = mB / C2_T, xB = mB - yB * C2_T;
                 const int baseA = (yA * P1_T + xA) * 10, baseB = (yB * P1_T + xB) * 10;
 #pragma unroll
@@ -914,8 +973,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 const int mtA = w2 + 8 * j, mtB = mtA + 4;
                 // Tiles on the bottom edge of a level hold fewer than 16 valid output rows: conv2 cells below the rows conv3 will
                 // read are skipped (M-tile m covers cells 16m.. of the 18-wide grid).  Uniform per wave, no barrier inside.
-                const bool hasB = mtB < 21 && 16 * mtB < lim2;  // j == 2: only wave role 0 has a second tile (M-tile 20)
-                const bool hasA = 16 * mtA < lim2;
+                const bool hasB = mtB < nmt2 && c0 + 16 * mtB < lim2;  // j == 2: only wave role 0 has a second tile (M-tile 20)
+                const bool hasA = mtA < nmt2 && c0 + 16 * mtA < lim2;
                 f32x4 accA = bias2v, accB = bias2v;
                 __builtin_amdgcn_sched_barrier(0);
                 if (!hasA) {
@@ -937,9 +996,9 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const int ra = mtA * 16 + kq * 4 + q;
+                    const int ra = c0 + mtA * 16 + kq * 4 + q;
                     if (hasA && ra < 324) RA[ra * C2_LD + l15] = prelu_t<UNIT>(accA[q], slope2, sel2);
-                    const int rb = mtB * 16 + kq * 4 + q;
+                    const int rb = c0 + mtB * 16 + kq * 4 + q;
                     if (hasB && rb < 324) RA[rb * C2_LD + l15] = prelu_t<UNIT>(accB[q], slope2, sel2);
                 }
             }
@@ -953,10 +1012,14 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         // next tile's input: global loads into registers only (RA is still read by phase 3)
         tile_nxt = __builtin_amdgcn_readfirstlane(next_tile_s);
         if (tile_nxt < t_end) { nxt = decode(tile_nxt); if (!(dbg_skip & 1)) issue_input(nxt); }
+        // the conv2 columns / rows the right / lower neighbour will not recompute (RA is read-only until the barrier that ends the
+        // tile) are copied behind the wave's last conv3 M-tile, in front of the last head chain
+        auto strips_get = [&]() __attribute__((always_inline)) {
+            if (feeds_next) copy_conv2(std::true_type{}, CC);
+            if (feeds_down) copy_rows2(std::true_type{});
+        };
 
         // ---- phase 3: conv3 + PReLU -> heads -> candidates, register to register -------------------------------------
-        // the conv2 columns the right neighbour will not recompute (RA is read-only until the barrier that ends the tile)
-        if (feeds_next) copy_conv2(std::true_type{});
         if (!(dbg_skip & 8)) {
             const float fscale = g.scale;
             const f32x4* T3 = reinterpret_cast<const f32x4*>(T3all);
@@ -1064,11 +1127,11 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             const int mt0 = wave, mt1 = wave + 4;
             if (2 * mt0 < vrows) {
                 f32x16 P0;
-                f32x4 hq0 = biasq;
+                f32x4 hq0 = T3[16 + hh];                        // head bias of this half's output group
                 conv3(mt0, P0, [](auto, auto) {});
                 if (2 * mt1 < vrows) {
                     f32x16 P1;
-                    f32x4 hq1 = biasq;
+                    f32x4 hq1 = T3[16 + hh];
                     conv3(mt1, P1, [&](auto SX, auto UU) __attribute__((always_inline)) {
                         constexpr int sx = decltype(SX)::value, u = decltype(UU)::value, h = sx * 6 + (u >> 1);
                         if constexpr ((u & 1) == 1 && h < 32) {          // (pinned: the scheduler would bunch the block instructions)
@@ -1077,6 +1140,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     });
+                    strips_get();
                     // ... and the second's chain has the first's softmax (VALU) in its dependency gaps
                     float p0 = trl_softmax2_p1(hq0[0], hq0[1]);
                     heads_all(P1, hq1);
@@ -1089,10 +1153,15 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                     emit(mt0, hq0, p0);
                     emit(mt1, hq1, trl_softmax2_p1(hq1[0], hq1[1]));
                 } else {
+                    strips_get();
                     heads_all(P0, hq0);
                     emit(mt0, hq0, trl_softmax2_p1(hq0[0], hq0[1]));
                 }
+            } else {
+                strips_get();
             }
+        } else {
+            strips_get();
         }
         stamp(6);
         __syncthreads();   // RA / RB are rewritten by the next tile
@@ -1145,6 +1214,8 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
         p.tiles_x = (g.ow + TS - 1) / TS;
         p.txmagic = (unsigned)((0x100000000ull + p.tiles_x - 1) / p.tiles_x);   // 2^32 for tiles_x == 1 wraps to 0: fixed up in sdiv()
         p.tile0 = tiles;
+        p.tiles_y = (g.oh + TS - 1) / TS;
+        p.bmagic = (unsigned)((0x100000000ull + BAND * p.tiles_x - 1) / (BAND * p.tiles_x));
         tiles += p.tiles_x * ((g.oh + TS - 1) / TS);
         p.pix0 = (int)pix;
         p.pix_pad = (int)(((long long)g.h * g.w + 63) & ~63ll);
@@ -1549,15 +1620,19 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     // (TRL_PNET_RUN / trl_debug_pnet_run override: tuning, and tests that exercise the carry path on small frames)
     static const int run_env = getenv("TRL_PNET_RUN") ? atoi(getenv("TRL_PNET_RUN")) : 0;
     const int auto_run = (total_tiles / 8) / 128;
-    a.run = c->pnet_run > 0 ? c->pnet_run : (run_env > 0 ? run_env : (auto_run < 1 ? 1 : (auto_run > 8 ? 8 : auto_run)));
+    a.run = c->pnet_run > 0 ? c->pnet_run : (run_env > 0 ? run_env : (auto_run < 1 ? 1 : (auto_run > 8 * BAND ? 8 * BAND : auto_run)));
     auto launch = [&](auto kern) {
-        if (xlds > 0) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DYN_LDS + xlds);
+        // static + dynamic LDS exceed the default 64 KB per workgroup
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, DYN_LDS + xlds) != hipSuccess) return false;
         kern<<<grid, 256, DYN_LDS + xlds, s>>>(a);
+        return true;
     };
-#define TRL_PK(U, N) do { if (dbg) launch(k_pnet_fused<U, N, true>); else launch(k_pnet_fused<U, N, false>); } while (0)
+    bool launched = false;
+#define TRL_PK(U, N) do { launched = dbg ? launch(k_pnet_fused<U, N, true>) : launch(k_pnet_fused<U, N, false>); } while (0)
     if (c->pnet_unit) { if (c->pnet_mono1) TRL_PK(true, false); else TRL_PK(true, true); }
     else { if (c->pnet_mono1) TRL_PK(false, false); else TRL_PK(false, true); }
 #undef TRL_PK
+    if (!launched) { trl_set_error("k_pnet_fused: %d bytes of dynamic LDS refused", DYN_LDS + xlds); return TRL_ERR_HIP; }
     TRL_LAUNCH_CHECK();
     if (ev) TRL_HIP(hipEventRecord(ev[3], s));
     return TRL_OK;
