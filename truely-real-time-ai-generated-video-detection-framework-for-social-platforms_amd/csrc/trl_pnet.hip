@@ -523,11 +523,11 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     // tile -> (frame, level, ty, tx), all on the scalar unit: divisions are multiply-high by host magic numbers
     // (an integer division would expand into a VALU float-reciprocal sequence, paid in MFMA issue slots), the
     // level is a branch-free count over a first-tile table held in SGPRs.
-    int lvl_t0[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) lvl_t0[i] = i < a.L ? a.lv[i].tile0 : 0x7fffffff;
+    // the level of a tile index: lane i holds the first tile of level i (lanes past the last level: INT_MAX), so the level is one
+    // compare and a ballot count -- sixteen thresholds in SGPRs pushed other uniform values into VGPRs and the whole decode onto the
+    // vector unit (84 VALU per tile beside the other workgroup's MFMAs)
+    const int lvl_t0v = lane < a.L ? a.lv[lane < 16 ? lane : 15].tile0 : 0x7fffffff;
     auto sdiv = [](int n, unsigned magic, int d) {
-        if (d == 1) return n;
         int q = (int)__umulhi((unsigned)n, magic);
         if (q * d > n) q--;
         if (n - q * d >= d) q++;
@@ -540,12 +540,12 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     struct TileId { int f, l, ty, tx, h, w, oh, ow, tiles_x, pix0, rib, rows; float scale; };   // rib: row inside the band, rows: tile rows of the band
     auto decode = [&](int tile) {
         TileId t;
-        t.f = sdiv(tile, a.tpf_magic, a.tiles_per_frame);
-        const int tt = tile - t.f * a.tiles_per_frame;
-        int lv = 0;
-#pragma unroll
-        for (int i = 1; i < 16; i++) lv += (tt >= lvl_t0[i]) ? 1 : 0;
-        t.l = __builtin_amdgcn_readfirstlane(lv);
+        // (readfirstlane: at the SGPR limit hipcc parks uniform values in VGPRs, and everything computed from one runs on the vector
+        // unit -- 84 VALU per tile for this decode; pinned to SGPRs here, it is scalar work again)
+        const int tpf = __builtin_amdgcn_readfirstlane(a.tiles_per_frame);
+        t.f = __builtin_amdgcn_readfirstlane(sdiv(tile, __builtin_amdgcn_readfirstlane(a.tpf_magic), tpf));
+        const int tt = tile - t.f * tpf;
+        t.l = __popcll(__ballot(tt >= lvl_t0v)) - 1;
         const PLevel& g = a.lv[t.l];
         t.h = g.h; t.w = g.w; t.oh = g.oh; t.ow = g.ow; t.tiles_x = g.tiles_x; t.pix0 = g.pix0; t.scale = g.scale;
         // band order: index inside the level -> (band, column, row inside the band); the last band of a level may be one row high
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         const int rb = tq - band * (BAND * t.tiles_x);
         t.rows = g.tiles_y - BAND * band < BAND ? g.tiles_y - BAND * band : BAND;
         static_assert(BAND == 2, "column of a band position: a shift");
-        t.tx = t.rows == 2 ? rb >> 1 : rb;
+        t.tx = __builtin_amdgcn_readfirstlane(t.rows == 2 ? rb >> 1 : rb);
         t.rib = rb - t.tx * t.rows;
         t.ty = BAND * band + t.rib;
         return t;
@@ -1201,6 +1201,10 @@ int trl_pnet_prepare(trl_ctx* c) {
     return TRL_OK;
 }
 
+// ceil(2^32 / d) for the kernel's sdiv(); d == 1 would need 2^32: 2^32 - 1 gives q = n - 1 (or 0), which sdiv's upward correction
+// step turns into n -- no special case on the device
+static unsigned sdiv_magic(int d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
 static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<uint32_t>* tab = nullptr) {
     const int L = trl_compute_levels(c, H, W);
     if (L > 16) { trl_set_error("more than 16 pyramid levels"); return TRL_ERR_INVALID; }
@@ -1212,10 +1216,10 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
         PLevel& p = a.lv[l];
         p.h = g.h; p.w = g.w; p.oh = g.oh; p.ow = g.ow;
         p.tiles_x = (g.ow + TS - 1) / TS;
-        p.txmagic = (unsigned)((0x100000000ull + p.tiles_x - 1) / p.tiles_x);   // 2^32 for tiles_x == 1 wraps to 0: fixed up in sdiv()
+        p.txmagic = sdiv_magic(p.tiles_x);
         p.tile0 = tiles;
         p.tiles_y = (g.oh + TS - 1) / TS;
-        p.bmagic = (unsigned)((0x100000000ull + BAND * p.tiles_x - 1) / (BAND * p.tiles_x));
+        p.bmagic = sdiv_magic(BAND * p.tiles_x);
         tiles += p.tiles_x * ((g.oh + TS - 1) / TS);
         p.pix0 = (int)pix;
         p.pix_pad = (int)(((long long)g.h * g.w + 63) & ~63ll);
@@ -1264,7 +1268,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
         p.scale = (float)g.scale;
     }
     a.tiles_per_frame = tiles;
-    a.tpf_magic = (unsigned)((0x100000000ull + tiles - 1) / tiles);
+    a.tpf_magic = sdiv_magic(tiles);
     a.pyr_stride = pix;
     a.work_per_frame = work;
     a.w1 = trl_w(c, "pnet.conv1.w")->p; a.w2 = trl_w(c, "pnet.conv2.w")->p; a.w3 = trl_w(c, "pnet.conv3.w")->p; a.wh = trl_w(c, "pnet.heads.w")->p;
