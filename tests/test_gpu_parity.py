@@ -165,6 +165,30 @@ def test_pnet_halo_carry_is_bit_exact(blob, oracle, run):
         _check_cascade(eng, oracle, truely_amd.synthetic.synthetic_frames(2, 720, 1280, seed=0))
 
 
+@pytest.mark.parametrize("thr", [0.011, 0.3, 0.6, 0.9, 0.989, 0.995])
+def test_pnet_threshold_prefilter_drops_nothing(blob, oracle, thr):
+    """The fused PNet kernel evaluates the softmax only for an M-tile (32 cells) in which some cell's logit difference comes within
+    reach of the first threshold (a bound 0.05 below ln(thr / (1 - thr)); off outside [0.01, 0.99]).  For thresholds across the
+    range the candidates of every level are exactly the cells whose oracle probability reaches thr, with the oracle's values."""
+    from truely_amd.engine import Engine
+    eng = Engine(blob, thresholds=(thr, 0.7, 0.7), cap_level=3072, cap_frame=3072)
+    H, W = 120, 160
+    fr = truely_amd.synthetic.synthetic_frames(2, H, W, seed=41)
+    eng.mtcnn_detect(fr)
+    total = 0
+    for f in range(2):
+        for l, (sc, h, w) in enumerate(oracle.scales(H, W)):
+            p_ref, r_ref = oracle.pnet_level(oracle.area_resample_norm(fr[f], 0, H, 0, W, h, w))
+            keep = np.flatnonzero(p_ref.reshape(-1) >= np.float32(thr))
+            rows = eng.level_cands(f, l)
+            assert np.array_equal(rows["cell"], keep), f"thr {thr} frame {f} level {l}: candidate cells"
+            assert np.array_equal(rows["score"], p_ref.reshape(-1)[keep])
+            assert np.array_equal(rows["reg"], r_ref.reshape(-1, 4)[keep])
+            total += len(keep)
+    if thr <= 0.6:
+        assert total > 0
+
+
 def test_landmarks_export(engine, oracle):
     """`mtcnn.detect(frame, landmarks=True)`: O-Net's five points, ordered like the boxes (largest area first)."""
     from truely_amd.mtcnn import MTCNN

@@ -95,6 +95,7 @@ struct PnetArgs {
     const float *w1, *w2, *w3, *wh;            // [Kpad][32] zero padded
     const float *b1, *b2, *b3, *bh, *s1, *s2, *s3;
     float thr; int cap;
+    float dthr;                                // logit-difference prefilter: no cell with logit1 - logit0 < dthr can reach thr (-inf: off)
     int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); read by the DBG instantiation only
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
     int32_t* xcd_next;                         // per-XCD dynamic tile cursor (8 counters, zeroed before the launch)
@@ -1093,9 +1094,12 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                 pn_static_for(std::make_integer_sequence<int, 32>{}, [&](auto H_T) __attribute__((always_inline)) { head_step(H_T, P, hq); });
             };
             // lanes 0..31: {logit0, logit1, reg0, reg1} of cell = lane; lanes 32..63: {reg2, reg3, -, -} of cell = lane - 32
-            // (the softmax is computed by every lane, branch-free -- lanes 32..63 on their two box offsets, finite and unused -- so
-            // that it can be scheduled into the gaps of a dependent head chain)
-            auto emit = [&](int mt, const f32x4& hq, float p) __attribute__((always_inline)) {
+            // The softmax (two exps and a division: ~55 VALU beside the other workgroup's MFMAs) runs only for an M-tile in which
+            // some cell's logit difference comes within reach of the threshold (a.dthr: a bound with a wide margin, fill_args) --
+            // one compare and a scalar branch for the ~90 % of the M-tiles that hold no candidate.
+            auto emit = [&](int mt, const f32x4& hq) __attribute__((always_inline)) {
+                if (__builtin_amdgcn_ballot_w64(lane < 32 && hq[1] - hq[0] >= a.dthr) == 0) return;
+                const float p = trl_softmax2_p1(hq[0], hq[1]);
                 const auto u2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(hq[0]), __float_as_uint(hq[0]), false, false);
                 const auto u3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(hq[1]), __float_as_uint(hq[1]), false, false);
                 if (lane < 32) {                                // one lane per cell of the 32-row tile
@@ -1141,21 +1145,13 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                         }
                     });
                     strips_get();
-                    // ... and the second's chain has the first's softmax (VALU) in its dependency gaps
-                    float p0 = trl_softmax2_p1(hq0[0], hq0[1]);
                     heads_all(P1, hq1);
-#pragma unroll
-                    for (int i = 0; i < 32; i++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two VALU
-                    }
-                    asm volatile("" : "+v"(p0));                             // (computed HERE, not sunk into the rare branch that reads it)
-                    emit(mt0, hq0, p0);
-                    emit(mt1, hq1, trl_softmax2_p1(hq1[0], hq1[1]));
+                    emit(mt0, hq0);
+                    emit(mt1, hq1);
                 } else {
                     strips_get();
                     heads_all(P0, hq0);
-                    emit(mt0, hq0, trl_softmax2_p1(hq0[0], hq0[1]));
+                    emit(mt0, hq0);
                 }
             } else {
                 strips_get();
@@ -1275,6 +1271,9 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
     a.b1 = trl_v(c, "pnet.conv1.b")->p; a.b2 = trl_v(c, "pnet.conv2.b")->p; a.b3 = trl_v(c, "pnet.conv3.b")->p; a.bh = trl_v(c, "pnet.heads.b")->p;
     a.s1 = trl_v(c, "pnet.prelu1")->p; a.s2 = trl_v(c, "pnet.prelu2")->p; a.s3 = trl_v(c, "pnet.prelu3")->p;
     a.thr = c->cfg.thr0; a.cap = c->cfg.cap_level;
+    // p = softmax(logit0, logit1)[1] >= thr needs logit1 - logit0 >= ln(thr / (1 - thr)) up to the rounding of the float softmax
+    // (~1e-6 relative); 0.05 below that bound the probability is short of thr by 0.05 thr (1 - thr) >= 4.9e-4 for thr in [0.01, 0.99]
+    a.dthr = (a.thr >= 0.01f && a.thr <= 0.99f) ? (float)(log((double)a.thr / (1.0 - (double)a.thr)) - 0.05) : -__builtin_inff();
     { const char* e = getenv("TRL_PNET_SKIP"); a.dbg_skip = e ? atoi(e) : 0; }
     a.lvl_cnt = c->cb.lvl_cnt; a.lvl_rec = c->cb.lvl_rec; a.flags = c->cb.flags;
     a.clk = c->pnet_clk;
