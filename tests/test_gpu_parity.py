@@ -134,13 +134,13 @@ def test_fused_pnet_kernel_maps_bit_exact(blob, oracle, H, W, seed):
             assert np.array_equal(rows["box"][:, 0], q1x) and np.array_equal(rows["box"][:, 3], q2y)
 
 
-@pytest.mark.parametrize("run", [2, 3, 5, 8, 16])
+@pytest.mark.parametrize("run", [2, 3, 5, 8, 24])
 def test_pnet_halo_carry_is_bit_exact(blob, oracle, run):
     """The fused PNet kernel hands a workgroup RUNS of consecutive tiles; a tile that follows its left neighbour takes the 4 pooled
     and 2 conv2 halo columns the neighbour already computed out of LDS instead of recomputing them (conv1 80 instead of 100
-    M-tiles, conv2 18 instead of 21); the tiles of a level are walked in bands of two tile rows, column by column, and the tile below
-    takes 4 pooled and 2 conv2 rows from the tile above the same way.  Large batches run with 16-tile runs; here the run length is
-    forced on small frames (levels one, two and seven tile rows high, odd run lengths that start on a lower tile): with
+    M-tiles, conv2 18 instead of 21); the tiles of a level are walked in bands of three tile rows, column by column, and a tile below another
+    takes 4 pooled and 2 conv2 rows from the tile above the same way.  Large batches run with 24-tile runs; here the run length is
+    forced on small frames (levels one, two and seven tile rows high: bands of 3, 2 and 1 rows; run lengths that start on any row of a band): with
     thr0 = 0 every cell of every level's probability / regression map is compared with the oracle, for run lengths that do and do
     not divide the tile rows, then the whole cascade on frames whose levels are many tiles wide (interior + edge tiles)."""
     from truely_amd.engine import Engine
@@ -161,7 +161,7 @@ def test_pnet_halo_carry_is_bit_exact(blob, oracle, run):
     eng.pnet_run(run)
     _check_cascade(eng, oracle, truely_amd.synthetic.synthetic_frames(3, 360, 640, seed=11))
     _check_cascade(eng, oracle, truely_amd.synthetic.synthetic_frames(2, 211, 333, seed=12))
-    if run in (8, 16):
+    if run in (8, 24):
         _check_cascade(eng, oracle, truely_amd.synthetic.synthetic_frames(2, 720, 1280, seed=0))
 
 

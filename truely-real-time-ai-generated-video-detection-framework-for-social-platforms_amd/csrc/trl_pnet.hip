@@ -52,11 +52,13 @@ static_assert(P1_T * P1_T * 10 <= REGION_B, "pooled tile fits region B");
 // (18 instead of 21 M-tiles).  Same values: every cell is the same fmaf chain over the same pixels whichever tile computes it.
 constexpr int CARRY_P = P1_T * 4 * 10;               // 800 floats: pooled rows x 4 columns x 10 channels
 constexpr int CARRY_C = C2_T * 2 * C2_LD;            // 612 floats: conv2 rows x 2 columns x 17 (padded channels)
-// Vertical carry (round 3): the tiles of a level are walked in BANDS of BAND tile rows, column by column (top tile, the tile below
-// it, then the next column), so the tile below follows its upper neighbour in the same workgroup: ITS first 4 pooled rows and
+// Vertical carry (round 3): the tiles of a level are walked in BANDS of BAND tile rows, column by column (top tile, the tiles below
+// it, then the next column), so a lower tile follows its upper neighbour in the same workgroup: ITS first 4 pooled rows and
 // 2 conv2 rows are the upper tile's last ones.  A tile with both carries computes 16 x 16 new pooled cells (one super unit per
-// wave and nothing else) and 16 x 16 new conv2 cells (16 M-tiles, four per wave).  The horizontal strips need one slot per band row.
-constexpr int BAND = 2;
+// wave and nothing else) and 16 x 16 new conv2 cells (16 M-tiles, four per wave).  The horizontal strips need one slot per band row:
+// three rows (two of three tiles carry vertically) fill the 80 KB a workgroup may use at two workgroups per CU; two rows were 1.5 %
+// slower, four do not fit.
+constexpr int BAND = 3;
 constexpr int VCARRY_P = 4 * P1_T * 10;              // 800 floats: 4 pooled rows x 20 columns x 10 channels (contiguous in the tile)
 constexpr int VCARRY_C = 2 * C2_T * C2_LD;           // 612 floats: 2 conv2 rows x 18 columns x 17
 constexpr int DYN_LDS = (144 * 32 + BAND * (CARRY_P + CARRY_C) + VCARRY_P + VCARRY_C) * 4;   // conv3 weights + the carry strips (dynamic: static LDS is capped at 64 KB)
@@ -554,8 +556,8 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         const int band = sdiv(tq, g.bmagic, BAND * t.tiles_x);
         const int rb = tq - band * (BAND * t.tiles_x);
         t.rows = g.tiles_y - BAND * band < BAND ? g.tiles_y - BAND * band : BAND;
-        static_assert(BAND == 2, "column of a band position: a shift");
-        t.tx = __builtin_amdgcn_readfirstlane(t.rows == 2 ? rb >> 1 : rb);
+        static_assert(BAND == 2 || BAND == 3, "column of a band position: rb / rows for rows in 1..3");
+        t.tx = __builtin_amdgcn_readfirstlane(t.rows == 3 ? (rb * 43691) >> 17 : (t.rows == 2 ? rb >> 1 : rb));   // (rb < 98304)
         t.rib = rb - t.tx * t.rows;
         t.ty = BAND * band + t.rib;
         return t;
@@ -677,14 +679,14 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         asm volatile("" : "+v"(ctid));
         const int vrows = (g.oh - ty * TS < TS) ? g.oh - ty * TS : TS;      // valid output rows of this tile
         // left neighbour = `rows` positions back in the band order, upper neighbour = the previous position
-        const bool carry = tx > 0 && (g.rib == 0 ? hs_tile[0] : hs_tile[1]) == tile - g.rows;
+        const bool carry = tx > 0 && (g.rib == 0 ? hs_tile[0] : (g.rib == 1 ? hs_tile[1] : hs_tile[BAND - 1])) == tile - g.rows;
         const bool vcarry = g.rib > 0 && vs_tile == tile - 1;
         const bool last_of_run = run_pos + 1 >= run_len;
         const bool feeds_next = run_pos + g.rows < run_len && tx + 1 < g.tiles_x;   // the right neighbour is a later tile of this run
         const bool feeds_down = !last_of_run && g.rib + 1 < g.rows;                   // the next tile of the run is the tile below
         float* const CP = CP0 + g.rib * (CARRY_P + CARRY_C);
         float* const CC = CP + CARRY_P;
-        if (feeds_next) { if (g.rib == 0) hs_tile[0] = tile; else hs_tile[1] = tile; }
+        if (feeds_next) { if (g.rib == 0) hs_tile[0] = tile; else if (g.rib == 1) hs_tile[1] = tile; else hs_tile[BAND - 1] = tile; }
         if (feeds_down) vs_tile = tile;
         int cursor = tile + 1 - t_begin;
         // Guided self-scheduling: near the end of the XCD's chunk the runs shrink (down to single tiles), so the workgroups of an XCD
