@@ -400,11 +400,15 @@ def main():
     if args.warmup > 0:
         run_steps(max(args.warmup, F))
     fence()
+    for e in engs:
+        e.pnet_span(reset=True)          # device-side sums of the fused PNet launches' execution spans: zeroed, read once after the region
     t0 = time.perf_counter()
     (out, d), acc = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    pnet_ms, pyr_ms, pnet_kernel_ms = acc["pnet_ms"], acc["pyramid_ms"], acc["pnet_kernel_ms"]
+    pnet_ms, pyr_ms = acc["pnet_ms"], acc["pyramid_ms"]
+    spans = [e.pnet_span() for e in engs]
+    pnet_kernel_ms, span_launches = sum(m for m, _ in spans), sum(k for _, k in spans)
     if use_dist:
         tdev = dev if args.backend == "nccl" else torch.device("cpu")
         tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
@@ -431,10 +435,12 @@ def main():
         tm = eng.timings()
         macs = pnet_macs(H, W, cfg["min_face"]) * n                  # per launch set of one step on this rank
         launches = max(1, tm["pnet_launches"])
-        # Duration of the dominant kernel per step: HIP events recorded around the launch on its stream, live over the timed
-        # region.  (With two batches in flight the pair also counts time the launch spends queued behind the other context's
-        # kernels; `--in-flight 1` and the committed rocprofv3 kernel stats give the kernel's own duration.)
-        use_span = pnet_kernel_ms > 0
+        # Duration of the dominant kernel per step, live over the timed region: the launch's EXECUTION SPAN on the device wall clock
+        # (first workgroup start to last workgroup end, stamped by the kernel itself and summed on the device) -- the quantity
+        # rocprofv3 reports as the kernel's duration, so the line and the committed kernel stats of the same command agree.  The
+        # HIP-event pair around the launch is reported next to it: with two batches in flight it also counts the time the launch
+        # waits behind the other context's kernels for CUs (the persistent grid needs every CU's registers).
+        use_span = pnet_kernel_ms > 0 and span_launches == args.steps * max(1, tm["pnet_launches"])
         pnet_s = (pnet_kernel_ms if use_span else pnet_ms) / 1e3 / args.steps
         achieved = 2.0 * macs / pnet_s / 1e12
         traffic = None
@@ -468,7 +474,7 @@ def main():
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "kernel": "k_pnet_fused (PNet over the pyramid: 83% of the conv FLOPs at 720p)",
                          "flop_per_step": 2.0 * macs, "kernel_ms_per_step": round(pnet_s * 1e3, 3), "launches_per_step": launches,
-                         "kernel_clock": "device wall clock span of the launch" if use_span else "HIP events",
+                         "kernel_clock": "device wall clock: first workgroup start to last workgroup end of every launch in the timed region (= rocprofv3's duration)" if use_span else "HIP events",
                          "kernel_ms_per_step_hip_events": round(pnet_ms / args.steps, 3),
                          "kernel_ms_alone": None if iso_ms is None else round(iso_ms, 3),
                          "frac_alone": None if iso_ms is None else round(2.0 * macs / (iso_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

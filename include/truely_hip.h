@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 5
+#define TRL_ABI_VERSION 6
 
 typedef enum {
     TRL_OK = 0,
@@ -193,6 +193,11 @@ int  trl_debug_pnet_run(trl_ctx* ctx, int run);
 /* execution span (first workgroup start -> last workgroup end, device wall clock) of the last fused PNet launch, in ms:
  * the kernel's duration as rocprofv3 reports it, free of stream-queueing time when several contexts share the GPU */
 int  trl_debug_pnet_kernel_ms(trl_ctx* ctx, float* ms);
+/* the same span summed on the device over every fused PNet launch of this context since the last reset (no per-call host
+ * round trip: two atomics per workgroup and a one-thread kernel per launch): *ms_sum milliseconds over *launches launches.
+ * Blocks until the device has finished the context's queued work only insofar as hipMemcpy does; bench.py reads it once,
+ * after its timed region. (ABI v6) */
+int  trl_debug_pnet_span(trl_ctx* ctx, int reset, double* ms_sum, int32_t* launches);
 
 #ifdef __cplusplus
 }

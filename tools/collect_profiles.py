@@ -56,6 +56,10 @@ def main():
         if os.path.exists(src):
             txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), src], capture_output=True, text=True, check=True).stdout
             open(os.path.join(DST, f"{tag}_sq_pmc_{sub}.txt"), "w").write(txt)
+    for name in ("pnet_phase_clocks.txt", "pnet_phase_pmc.txt", "front_ablation.txt", "batch_sweep_config1.json", "batch_sweep_config4.json"):
+        src = os.path.join(SRC, name)
+        if os.path.exists(src) and os.path.getsize(src) > 0:
+            shutil.copy(src, os.path.join(DST, f"{tag}_{name}"))
     for name in ("facenet_ms.txt", "facenet_stamps.txt"):
         src = os.path.join(SRC, name)
         if os.path.exists(src):

@@ -43,3 +43,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_fn1024 -o s -f cs
 timeout -k 10 200 python tools/time_facenet.py 8 1024 >> $O/facenet_ms.txt 2>&1
 timeout -k 10 200 python tools/fn_stamps.py 2 5 16 58 60 61 2>&1 | grep -E "launch|fn stamps" > $O/facenet_stamps.txt
 echo "facenet done"
+# where the waves of the fused PNet kernel spend their time (DBG instantiation: shader clocks per phase and barrier), its phase
+# ablation with SQ counters, and the batch sweeps
+TRL_PNET_CLOCK=1 timeout -k 10 300 python bench.py --steps 10 --warmup 2 $B --in-flight 1 --embed-group 1 > $O/bench_pnet_clock.json 2> $O/pnet_clock.err; grep TRL_PNET_CLOCK $O/pnet_clock.err > $O/pnet_phase_clocks.txt
+bash tools/pnet_phase_pmc.sh > /dev/null 2>&1; cp gpurun_out/pnet_phase_pmc.txt $O/pnet_phase_pmc.txt
+bash tools/front_ablation.sh > /dev/null 2>&1; cp gpurun_out/front_ablation.txt $O/front_ablation.txt
+timeout -k 10 300 python tools/batch_sweep.py 1 $O/batch_sweep_config1.json > /dev/null 2>&1
+timeout -k 10 300 python tools/batch_sweep.py 4 $O/batch_sweep_config4.json > /dev/null 2>&1
+echo "phase evidence done"

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "trl_debug_stage_totals": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "trl_debug_pnet_run": (C.c_int, [_vp, _i]),
     "trl_debug_pnet_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "trl_debug_pnet_span": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -81,7 +82,7 @@ def load(path: str | None = None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.trl_abi_version() != 5:
+    if lib.trl_abi_version() != 6:
         raise ImportError("libtruely_hip ABI mismatch")
     _lib = lib
     return lib

@@ -46,9 +46,11 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
     TRL_HIP(hipSetDevice(cfg->device));
     trl_ctx* c = new trl_ctx();
     c->cfg = *cfg;
-    // diagnostic only: the clocked PNet instantiation (device-wall-clock span of the launch) runs when TRL_PNET_CLOCK is set
-    if (getenv("TRL_PNET_CLOCK") && (hipMalloc((void**)&c->pnet_clk, 8 * 40) != hipSuccess || hipMemset(c->pnet_clk, 0, 8 * 40) != hipSuccess)) c->pnet_clk = nullptr;
-    if (hipMalloc((void**)&c->pnet_cursor, 64) != hipSuccess || hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess ||
+    // execution span of every fused PNet launch (two atomics per workgroup, summed on the device: trl_debug_pnet_span);
+    // TRL_PNET_CLOCK additionally selects the DBG instantiation with per-phase wave clocks
+    c->pnet_prof = getenv("TRL_PNET_CLOCK") != nullptr;
+    if (hipMalloc((void**)&c->pnet_clk, 8 * 40) != hipSuccess || hipMemset(c->pnet_clk, 0, 8 * 40) != hipSuccess || hipMemset(c->pnet_clk, 0xFF, 8) != hipSuccess ||
+        hipMalloc((void**)&c->pnet_cursor, 64) != hipSuccess || hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess ||
         hipEventCreate(&c->ev_call0) != hipSuccess || hipEventCreate(&c->ev_call1) != hipSuccess) {
         trl_set_error("context allocation failed: %s", hipGetErrorString(hipGetLastError()));
         trl_destroy(c);                      // frees whatever was created
@@ -72,7 +74,7 @@ int trl_destroy(trl_ctx* c) {
     if (c->pnet_clk) {
         // TRL_PNET_CLOCK: where the waves of the fused PNet launches spent their time (shader clocks per tile and wave, DBG instantiation)
         unsigned long long t[40];
-        if (hipMemcpy(t, c->pnet_clk, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[2 + 32] > 0) {
+        if (c->pnet_prof && hipMemcpy(t, c->pnet_clk, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[2 + 32] > 0) {
             static const char* nm[8] = {"phase0", "barrier0", "phase1", "barrier1", "phase2", "barrier2", "phase3", "barrier3"};
             const double tiles = (double)t[2 + 32];
             fprintf(stderr, "[TRL_PNET_CLOCK] shader clocks per tile (wave 0..3), %.0f workgroup-tiles\n", tiles);
@@ -315,12 +317,12 @@ static void collect_timings(trl_ctx* c) {
     }
     c->last_ms[0] = pnet_ms; c->last_ms[1] = call_ms; c->last_ms[2] = (float)launches; c->last_ms[3] = pyr_ms;
     c->pnet_kernel_ms = 0.f;
-    if (c->cfg.pnet_mode == 0 && c->pnet_clk) {
-        unsigned long long t[2] = {0, 0};
+    if (c->cfg.pnet_mode == 0 && c->pnet_clk && c->pnet_prof) {   // diagnostic mode only: a blocking copy per call (the last launch's span)
+        unsigned long long t = 0;
         int khz = 0;
-        if (hipMemcpy(t, c->pnet_clk, sizeof t, hipMemcpyDeviceToHost) == hipSuccess &&
-            hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device) == hipSuccess && khz > 0 && t[1] > t[0])
-            c->pnet_kernel_ms = (float)((double)(t[1] - t[0]) / (double)khz);
+        if (hipMemcpy(&t, c->pnet_clk + 38, sizeof t, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device) == hipSuccess && khz > 0)
+            c->pnet_kernel_ms = (float)((double)t / (double)khz);
     }
 }
 
@@ -683,6 +685,21 @@ int trl_debug_stage_totals(trl_ctx* c, int32_t* h_out2) {
 int trl_debug_pnet_run(trl_ctx* c, int run) {
     if (!c || run < 0 || run > 64) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
     c->pnet_run = run;
+    return TRL_OK;
+}
+
+int trl_debug_pnet_span(trl_ctx* c, int reset, double* ms_sum, int32_t* launches) {
+    if (!c || !ms_sum || !launches) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
+    *ms_sum = 0.0; *launches = 0;
+    if (!c->pnet_clk) return TRL_OK;
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    unsigned long long t[2] = {0, 0};
+    int khz = 0;
+    TRL_HIP(hipMemcpy(t, c->pnet_clk + 36, sizeof t, hipMemcpyDeviceToHost));
+    TRL_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device));
+    if (khz > 0) *ms_sum = (double)t[0] / (double)khz;
+    *launches = (int32_t)t[1];
+    if (reset) TRL_HIP(hipMemset(c->pnet_clk + 36, 0, 16));
     return TRL_OK;
 }
 

@@ -51,7 +51,8 @@ struct trl_ctx {
     int pnet_unit = 0;               // no PNet PReLU slope above 1 (negative ones allowed): prelu(v) == max(v, s v)
     int pnet_run = 0;                // > 0: tiles per cursor fetch of the fused PNet launch (trl_debug_pnet_run); 0 = automatic
     int32_t* pnet_cursor = nullptr;           // device: 8 per-XCD tile cursors of the fused PNet launch
-    unsigned long long* pnet_clk = nullptr;   // device: first-start / last-end wall clock of the fused PNet launch
+    unsigned long long* pnet_clk = nullptr;   // device: [0] first-start / [1] last-end wall clock of the fused PNet launch in flight, [2..35] phase clocks (DBG), [36] summed spans, [37] launches
+    bool pnet_prof = false;                   // TRL_PNET_CLOCK: the DBG instantiation with per-phase wave clocks
     float pnet_kernel_ms = 0.f;      // its span in ms (collect_timings)
     int dbg_poison = -1;             // >= 0 after trl_debug_poison: byte written into every newly allocated workspace
     // Optimistic capacities of the R-Net / O-Net candidate batches (candidates per frame): launches are sized by them and

@@ -102,7 +102,8 @@ struct PnetArgs {
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
     int32_t* xcd_next;                         // per-XCD dynamic tile cursor (8 counters, zeroed before the launch)
     int run;                                   // consecutive tiles a workgroup takes per cursor fetch (>= 1)
-    unsigned long long* clk;                   // [0] = earliest workgroup start, [1] = latest workgroup end (device wall clock)
+    unsigned long long* clk;                   // [0] = earliest workgroup start, [1] = latest workgroup end (device wall clock); DBG: [2..] phase clocks
+    int prof;                                  // DBG instantiation: accumulate the per-phase wave clocks
 };
 
 // ---- pyramid -------------------------------------------------------------------------------------
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every M-tile index below is SALU work
     const int dbg_skip = DBG ? a.dbg_skip : 0;                   // a compile-time 0 in production
-    if (DBG && a.clk && tid == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());   // execution span of the launch, queueing excluded
+    if (tid == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());   // execution span of the launch (what rocprofv3 calls its duration): two atomics per workgroup, no reply awaited
     const int l15 = lane & 15, kq = lane >> 4;      // 16x16x4 operand coordinates
     const int l31 = lane & 31, hh = lane >> 5;      // 32x32x2 operand coordinates
 
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     for (int i = 0; i < BAND; i++) hs_tile[i] = -1;
     // DBG + TRL_PNET_CLOCK: shader-clock time of every wave in each phase and at each barrier, summed over the launch (clk[2 + 8 wave + k])
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = 0;
-    const bool prof = DBG && a.clk != nullptr;
+    const bool prof = DBG && a.prof != 0;
     auto stamp = [&](int k) {
         if (DBG && prof) { const unsigned long long t = clock64(); pt[k] += t - pt_last; pt_last = t; }
     };
@@ -1170,10 +1171,18 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         for (int k = 0; k < 8; k++) atomicAdd(&a.clk[2 + 8 * wave + k], pt[k]);
         if (wave == 0) atomicAdd(&a.clk[2 + 32], (unsigned long long)rot);
     }
-    if (DBG && a.clk && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
+    if (tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
 
 }  // namespace
+
+// after a fused launch: [36] += its span, [37] += 1, [38] = its span; the start / end stamps are re-armed for the next launch
+__global__ void k_pnet_span(unsigned long long* clk) {
+    const unsigned long long t0 = clk[0], t1 = clk[1];
+    const unsigned long long d = t1 > t0 ? t1 - t0 : 0ull;
+    clk[36] += d; clk[37] += 1ull; clk[38] = d;
+    clk[0] = ~0ull; clk[1] = 0ull;
+}
 
 int trl_pnet_prepare(trl_ctx* c) {
     for (const char* n : {"pnet.conv1.w", "pnet.conv2.w", "pnet.conv3.w", "pnet.heads.w"}) {
@@ -1278,7 +1287,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
     a.dthr = (a.thr >= 0.01f && a.thr <= 0.99f) ? (float)(log((double)a.thr / (1.0 - (double)a.thr)) - 0.05) : -__builtin_inff();
     { const char* e = getenv("TRL_PNET_SKIP"); a.dbg_skip = e ? atoi(e) : 0; }
     a.lvl_cnt = c->cb.lvl_cnt; a.lvl_rec = c->cb.lvl_rec; a.flags = c->cb.flags;
-    a.clk = c->pnet_clk;
+    a.clk = c->pnet_clk; a.prof = c->pnet_prof ? 1 : 0;
     a.xcd_next = c->pnet_cursor;
     return TRL_OK;
 }
@@ -1613,14 +1622,10 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     if (grid > ((total_tiles + 7) / 8) * 8) grid = ((total_tiles + 7) / 8) * 8;
     if (grid < 8) grid = 8;
     TRL_HIP(hipMemsetAsync(c->pnet_cursor, 0, 8 * sizeof(int32_t), s));
-    if (c->pnet_clk) {   // device-clock span of the launch (what rocprofv3 reports as the kernel's duration)
-        TRL_HIP(hipMemsetAsync(c->pnet_clk, 0xFF, 8, s));
-        TRL_HIP(hipMemsetAsync(c->pnet_clk + 1, 0, 8, s));
-    }
     if (ev) TRL_HIP(hipEventRecord(ev[2], s));   // the event pair brackets the kernel alone (HIP events on the launch's stream)
     static const int xlds = getenv("TRL_PNET_XLDS") ? atoi(getenv("TRL_PNET_XLDS")) : 0;   // experiment: unused dynamic LDS, lowers the resident workgroups per CU
     // instantiation: slopes all <= 1 or not, a negative conv1 slope or not, diagnostics (TRL_PNET_CLOCK / TRL_PNET_SKIP) or not
-    const bool dbg = c->pnet_clk || a.dbg_skip;
+    const bool dbg = c->pnet_prof || a.dbg_skip;
     // Tiles per cursor fetch: 8 consecutive tiles share 7 carries; small batches keep single tiles so that every CU gets work
     // (TRL_PNET_RUN / trl_debug_pnet_run override: tuning, and tests that exercise the carry path on small frames)
     static const int run_env = getenv("TRL_PNET_RUN") ? atoi(getenv("TRL_PNET_RUN")) : 0;
@@ -1640,5 +1645,7 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     if (!launched) { trl_set_error("k_pnet_fused: %d bytes of dynamic LDS refused", DYN_LDS + xlds); return TRL_ERR_HIP; }
     TRL_LAUNCH_CHECK();
     if (ev) TRL_HIP(hipEventRecord(ev[3], s));
+    k_pnet_span<<<1, 1, 0, s>>>(c->pnet_clk);   // fold the launch's span into the running sums, re-arm the two stamps
+    TRL_LAUNCH_CHECK();
     return TRL_OK;
 }

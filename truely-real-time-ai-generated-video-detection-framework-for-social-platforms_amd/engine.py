@@ -330,6 +330,13 @@ class Engine:
             minl *= self.cfg.factor
         return k
 
+    def pnet_span(self, reset: bool = False):
+        """(milliseconds, launches): execution spans of the fused PNet launches of this context since the last reset, summed on
+        the device (first workgroup start to last workgroup end: the duration rocprofv3 reports for the kernel)."""
+        ms, k = C.c_double(), C.c_int32()
+        _lib.check(self.lib.trl_debug_pnet_span(self._h, 1 if reset else 0, C.byref(ms), C.byref(k)))
+        return float(ms.value), int(k.value)
+
     def timings(self):
         t = (C.c_float * 4)()
         _lib.check(self.lib.trl_debug_timings(self._h, t))
