@@ -187,8 +187,9 @@ int  trl_debug_crop_aligned(trl_ctx* ctx, const uint8_t* d_frames, int n, int H,
 int  trl_debug_timings(trl_ctx* ctx, float* out4);
 /* R-Net / O-Net candidate totals of the last call over the whole batch: h_out2[0] = boxes that entered stage 2, [1] = stage 3 */
 int  trl_debug_stage_totals(trl_ctx* ctx, int32_t* h_out2);
-/* test / tuning hook: consecutive tiles a workgroup of the fused PNet launch takes per cursor fetch (0 = automatic: 8 for large
- * batches, 1 for small ones).  With runs > 1 a tile reuses the halo columns its left neighbour computed; same results. */
+/* test / tuning hook: consecutive tiles (band order: three tile rows, column by column) a workgroup of the fused PNet launch takes
+ * per cursor fetch (0 = automatic: 24 for large batches, down to 1 for small ones).  With runs > 1 a tile reuses the halo columns /
+ * rows its left / upper neighbour computed; same results. */
 int  trl_debug_pnet_run(trl_ctx* ctx, int run);
 /* execution span (first workgroup start -> last workgroup end, device wall clock) of the last fused PNet launch, in ms:
  * the kernel's duration as rocprofv3 reports it, free of stream-queueing time when several contexts share the GPU */

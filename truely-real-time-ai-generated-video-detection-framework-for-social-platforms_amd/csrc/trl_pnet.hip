@@ -461,7 +461,7 @@ __device__ __forceinline__ void pn_static_for(std::integer_sequence<int, I...>, 
 template <bool UNIT, bool NEG1, bool DBG>
 __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     __shared__ __attribute__((aligned(16))) float RA[REGION_A];   // input tile [42][42][3]  ->  conv2 out [324][17]
-    __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10]        ->  conv3 staging [4][32][33]
+    __shared__ __attribute__((aligned(16))) float RB[REGION_B];   // pooled [400][10] (+ the reach of conv2's zero-weight k padding)
     __shared__ __attribute__((aligned(16))) float T3all[72];      // conv3 bias[32], PReLU slopes[32] (a lane's 16 channels differ per register), head bias[8] (phase 3)
     extern __shared__ __attribute__((aligned(16))) float DYN[];  // DYN_LDS bytes, then whatever a tuning run pads (TRL_PNET_XLDS)
     float* const B3S = DYN;                                       // conv3 weights [k][cout]: read per k-chain batch, not held in VGPRs
@@ -649,10 +649,11 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
             if (SAVE) *c = *t; else *t = *c;
         }
     };
-    // Dynamic schedule inside the XCD's chunk: a workgroup takes the next RUN of a.run consecutive tiles of its XCD from an atomic
-    // cursor, so one that starts late (another stream's kernel still on its CU) or loses time simply processes fewer runs; inside a
-    // run the next tile is tile + 1 (its left neighbour's carry strips are then in LDS); the cursor value for the tile after a run
-    // is fetched at the top of the run's last tile and travels through LDS (the loop's own barriers order it).
+    // Dynamic schedule inside the XCD's chunk: a workgroup takes the next RUN of a.run consecutive tile indices (band order: see
+    // decode) of its XCD from an atomic cursor, so one that starts late (another stream's kernel still on its CU) or loses time
+    // simply processes fewer runs; inside a run the next tile is tile + 1 (the tile below, or the top of the next column: its
+    // neighbours' carry strips are then in LDS); the cursor value for the tile after a run is fetched at the top of the run's
+    // last tile and travels through LDS (the loop's own barriers order it).
     __shared__ int next_tile_s;
     int run_len = a.run;
     if (tid == 0) next_tile_s = t_begin + atomicAdd(&a.xcd_next[xcd], run_len);
@@ -1626,7 +1627,8 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     static const int xlds = getenv("TRL_PNET_XLDS") ? atoi(getenv("TRL_PNET_XLDS")) : 0;   // experiment: unused dynamic LDS, lowers the resident workgroups per CU
     // instantiation: slopes all <= 1 or not, a negative conv1 slope or not, diagnostics (TRL_PNET_CLOCK / TRL_PNET_SKIP) or not
     const bool dbg = c->pnet_prof || a.dbg_skip;
-    // Tiles per cursor fetch: 8 consecutive tiles share 7 carries; small batches keep single tiles so that every CU gets work
+    // Tiles per cursor fetch: a run of 24 = 8 columns of a 3-row band (7 of 8 columns carry horizontally, 2 of 3 rows vertically);
+    // small batches keep shorter runs, down to single tiles, so that every CU gets work
     // (TRL_PNET_RUN / trl_debug_pnet_run override: tuning, and tests that exercise the carry path on small frames)
     static const int run_env = getenv("TRL_PNET_RUN") ? atoi(getenv("TRL_PNET_RUN")) : 0;
     const int auto_run = (total_tiles / 8) / 128;
