@@ -1,11 +1,13 @@
 """Per-kernel register / LDS / scratch use of libtruely_hip.so, read from the code object's metadata notes.
 
-    python tools/kernel_resources.py [filter]      # exits 1 if any kernel uses scratch (spills)
+    python tools/kernel_resources.py [filter]      # exits 1 if any production kernel touches scratch (spills)
 
 hipcc embeds one gfx950 code object per translation unit in the .so's .hip_fatbin section (clang offload bundles); their
 AMDGPU metadata notes are printed with llvm-readelf.  Every PRODUCTION kernel is expected to have
 private_segment_fixed_size == 0; the diagnostic instantiations of k_pnet_fused (last template argument true:
-clock stamps + phase ablations, selected by TRL_PNET_CLOCK / TRL_PNET_SKIP only) are reported but may spill a few registers."""
+clock stamps + phase ablations, selected by TRL_PNET_CLOCK / TRL_PNET_SKIP only) are reported but may spill a few registers.
+A kernel whose metadata reserves a private segment is disassembled: LLVM sometimes leaves the frame of SGPR spill slots that all
+went to VGPR lanes (no memory instruction touches it) -- reported as "frame never accessed" and not counted as a spill."""
 import os
 import re
 import struct
@@ -39,17 +41,25 @@ def code_objects(lib=LIB):
         pos = d.find(magic, pos + 1)
 
 
+def scratch_accesses(co_path, name):
+    """Number of instructions of kernel `name` that address the private segment (scratch_* or buffer_* ... offen/s[0:3] forms)."""
+    dis = subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", f"--disassemble-symbols={name}", co_path], text=True)
+    return sum(1 for l in dis.splitlines() if re.search(r"\bscratch_(load|store)|\bbuffer_(load|store)\S*\s.*\boffen\b", l))
+
+
 def kernels(lib=LIB):
     out = []
     for co in code_objects(lib):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
             f.write(co); f.flush()
             txt = subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", f.name], text=True)
-        for blk in txt.split("- .agpr_count:")[1:]:
-            g = lambda k: re.search(rf"\.{k}:\s+(\S+)", blk)
-            out.append(dict(name=g("name").group(1), vgpr=int(g("vgpr_count").group(1)), agpr=int(blk.split()[0]),
-                            sgpr=int(g("sgpr_count").group(1)), lds=int(g("group_segment_fixed_size").group(1)),
-                            scratch=int(g("private_segment_fixed_size").group(1))))
+            for blk in txt.split("- .agpr_count:")[1:]:
+                g = lambda k: re.search(rf"\.{k}:\s+(\S+)", blk)
+                k = dict(name=g("name").group(1), vgpr=int(g("vgpr_count").group(1)), agpr=int(blk.split()[0]),
+                         sgpr=int(g("sgpr_count").group(1)), lds=int(g("group_segment_fixed_size").group(1)),
+                         scratch=int(g("private_segment_fixed_size").group(1)))
+                k["accesses"] = scratch_accesses(f.name, k["name"]) if k["scratch"] else 0
+                out.append(k)
     return out
 
 
@@ -60,7 +70,8 @@ if __name__ == "__main__":
         dem = subprocess.run(["c++filt", k["name"]], capture_output=True, text=True).stdout.strip()
         if flt and flt not in dem:
             continue
-        print(f"{dem[:110]:110s} vgpr {k['vgpr']:3d} agpr {k['agpr']:3d} sgpr {k['sgpr']:3d} lds {k['lds']:6d} scratch {k['scratch']}")
+        note = "" if not k["scratch"] else (f" ({k['accesses']} scratch instructions)" if k["accesses"] else " (frame never accessed)")
+        print(f"{dem[:110]:110s} vgpr {k['vgpr']:3d} agpr {k['agpr']:3d} sgpr {k['sgpr']:3d} lds {k['lds']:6d} scratch {k['scratch']}{note}")
         diagnostic = "k_pnet_fused<" in dem and dem.split(">(")[0].endswith("true")
-        bad += k["scratch"] > 0 and not diagnostic
+        bad += k["accesses"] > 0 and not diagnostic
     sys.exit(1 if bad else 0)

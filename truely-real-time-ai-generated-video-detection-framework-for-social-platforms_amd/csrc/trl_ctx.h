@@ -71,6 +71,8 @@ struct trl_ctx {
     } pend;
     uint32_t* pyr_tab = nullptr;     // pyramid bin-edge tables for the last (H, W)
     int pyr_tab_H = 0, pyr_tab_W = 0;
+    // one-pass kernel for the finest levels (k_pyramid_fine): ownership table inside pyr_tab, source tile shape; nlev == 0: not usable for this shape
+    struct { int nlev = 0, own0 = 0, band_cols = 0, strip_rows = 0, n_bands = 0, n_strips = 0; } pyr_fine;
 };
 
 int trl_ensure(trl_ctx* c, Arena& a, size_t bytes);   // grow (never while blocks of `a` are live)

@@ -385,6 +385,142 @@ __global__ __launch_bounds__(256) void k_pyramid0(const uint8_t* __restrict__ fr
     pyr_level0<ROWS, FOUR>(frames, a, a.g, tab, pyr, a.f0 + blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
+// The three finest levels in ONE pass over the source (round 3).  A workgroup owns a source tile (a band of `band_cols` source
+// columns x a strip of `strip_rows` source rows); wave L walks the tile's source rows for level L: its 64 lanes are the output
+// columns of that level whose bins START in the band, its output rows those whose bins start in the strip (a bin may run past the
+// tile: the wave simply reads on).  The three waves read the same source rows at about the same time, so the frame bytes come from
+// HBM once and from the CU's L1 / the L2 for the other two levels -- the per-level kernels above re-read the whole frame chunk
+// from the Infinity Cache for every level.  Inside a wave: a source row's three channel sums are formed once and added to the (at
+// most two: H >= h) bins that contain it, column quantities are per-lane constants, row quantities wave-uniform (SALU); integer
+// sums, the same division and normalisation (pyr_norm): bit-identical pixels.  D source rows in flight per lane.
+struct PyrFineArgs {
+    int H, W, n_frames, f0; long long pyr_stride;
+    int nlev, band_cols, strip_rows, n_bands, n_strips;
+    int own0;                      // offset in `tab` of the ownership table: [level][band] (ox_lo, ox_hi), then [level][strip] (oy_lo, oy_hi)
+    PLevel g[3];
+};
+template <bool FOUR>
+__device__ __forceinline__ void pyr_fine_wave(const uint8_t* __restrict__ frames, const PyrFineArgs& a, const PLevel& g, const uint32_t* __restrict__ tab,
+                                              PyrPx* __restrict__ pyr, int f, int ox_lo, int ox_hi, int oy0, int oy1, int lane, bool pad_wave) {
+    constexpr int ND = FOUR ? 5 : 4, D = 6;                                          // (4 and 8 rows in flight measured the same)
+    PyrPx* const out = pyr + ((long long)f * a.pyr_stride + g.pix0);
+    if (pad_wave && g.h * g.w + lane < g.pix_pad) pyr_store(out + (g.h * g.w + lane), make_float4(0.f, 0.f, 0.f, 0.f));   // the level's padding pixels: zeros, as ever
+    if (oy0 >= oy1 || ox_lo >= ox_hi) return;                                        // wave-uniform
+    const int ox = ox_lo + lane;
+    const bool valid = ox < ox_hi;
+    // ---- column quantities: constants of the lane for the whole strip ----
+    const uint32_t tx = tab[g.xtab0 + (valid ? ox : ox_hi - 1)];
+    const int xs = tx & 0xFFFF, kw = (int)(tx >> 16) - xs;
+    const long long fbase = (long long)f * a.H * a.W * 3;
+    const int fb3 = (int)(fbase & 3);
+    const char* fptr = reinterpret_cast<const char*>(frames) + (fbase - fb3);      // dword aligned, scalar
+    const unsigned row_bytes = (unsigned)a.W * 3u;
+    const unsigned lx = (unsigned)(xs * 3 + fb3);                                   // the bin's first byte inside a source row, from fptr
+    const bool wA = kw == g.kwA;
+    const unsigned vm0 = wA ? g.vmA[0] : g.vmB[0], vm1 = wA ? g.vmA[1] : g.vmB[1], vm2 = wA ? g.vmA[2] : g.vmB[2], vm3 = wA ? g.vmA[3] : g.vmB[3];
+    const bool lastf = f == a.n_frames - 1;
+    const long long lim = ((((long long)a.n_frames * a.H * a.W * 3) - 1) >> 2) * 4 - (fbase - fb3);   // last dword holding frame bytes, from fptr
+    // a source row: ND aligned dwords from the bin's first byte.  SLOW = a strip that reads the last row of the last frame, which
+    // may not be read past the end of the buffer: clamped dwords (the pipelined loop stays single-path)
+    auto fetch = [&](auto SLOW_T, int y, unsigned (&w)[ND]) __attribute__((always_inline)) {
+        const unsigned lo = (unsigned)y * row_bytes + lx;
+        const char* q = fptr + (lo & ~3u);
+        if (!decltype(SLOW_T)::value) {
+            const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(q);
+            w[0] = v4[0]; w[1] = v4[1]; w[2] = v4[2]; w[3] = v4[3];
+            if (FOUR) w[ND - 1] = *reinterpret_cast<const uint32_t*>(q + 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < ND; j++) {
+                const long long o = (long long)(lo & ~3u) + 4 * j;
+                w[j] = *reinterpret_cast<const uint32_t*>(fptr + (o < lim ? o : lim));
+            }
+        }
+    };
+    auto rowsum = [&](int y, const unsigned (&w)[ND], unsigned& r0, unsigned& r1, unsigned& r2) __attribute__((always_inline)) {
+        const unsigned sh = ((unsigned)y * row_bytes + lx) & 3u;
+        const unsigned d0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh) & vm0;
+        const unsigned d1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh) & vm1;
+        const unsigned d2 = __builtin_amdgcn_alignbyte(w[3], w[2], sh) & vm2;
+        r0 = __builtin_amdgcn_udot4(d0, 0x01000001u, 0u, false); r1 = __builtin_amdgcn_udot4(d0, 0x00000100u, 0u, false);
+        r2 = __builtin_amdgcn_udot4(d0, 0x00010000u, 0u, false);
+        r0 = __builtin_amdgcn_udot4(d1, 0x00010000u, r0, false); r1 = __builtin_amdgcn_udot4(d1, 0x01000001u, r1, false);
+        r2 = __builtin_amdgcn_udot4(d1, 0x00000100u, r2, false);
+        r0 = __builtin_amdgcn_udot4(d2, 0x00000100u, r0, false); r1 = __builtin_amdgcn_udot4(d2, 0x00010000u, r1, false);
+        r2 = __builtin_amdgcn_udot4(d2, 0x01000001u, r2, false);
+        if (FOUR) {
+            const unsigned d3 = __builtin_amdgcn_alignbyte(w[4], w[3], sh) & vm3;
+            r0 = __builtin_amdgcn_udot4(d3, 0x01000001u, r0, false); r1 = __builtin_amdgcn_udot4(d3, 0x00000100u, r1, false);
+            r2 = __builtin_amdgcn_udot4(d3, 0x00010000u, r2, false);
+        }
+    };
+    // ---- row quantities: wave-uniform ----
+    auto edges = [&](int oy, int& ys, int& ye) __attribute__((always_inline)) {     // bin [ys, ye) of output row oy; past the strip: never
+        if (oy >= oy1) { ys = 0x7fffffff; ye = 0x7fffffff; return; }
+        if (g.arith) {
+            ys = (int)__umulhi((unsigned)(oy * a.H), g.hmagic);
+            ye = (int)__umulhi((unsigned)((oy + 1) * a.H + g.h - 1), g.hmagic);
+        } else {
+            const uint32_t t = tab[g.ytab0 + oy];
+            ys = (int)(t & 0xFFFF); ye = (int)(t >> 16);
+        }
+        ys = __builtin_amdgcn_readfirstlane(ys); ye = __builtin_amdgcn_readfirstlane(ye);
+    };
+    int ys_first, ye_first, ys_last, yend;
+    edges(oy0, ys_first, ye_first);
+    edges(oy1 - 1, ys_last, yend);                                                   // the wave's source rows: [ys_first, yend)
+    auto run = [&](auto SLOW_T) __attribute__((always_inline)) {
+        int oy = oy0, ys_c = ys_first, ye_c = ye_first, ys_n, ye_n;
+        edges(oy + 1, ys_n, ye_n);
+        unsigned c0 = 0, c1 = 0, c2 = 0, n0 = 0, n1 = 0, n2 = 0;                    // channel sums of the current bin and of the next one
+        unsigned ring[D][ND];
+        const int ycl = yend - 1;                                                    // rows past the wave's last bin are never touched
+#pragma unroll
+        for (int k = 0; k < D; k++) fetch(SLOW_T, ys_first + k < ycl ? ys_first + k : ycl, ring[k]);
+        for (int yb = ys_first; yb < yend; yb += D) {
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const int y = yb + k;                                                // wave-uniform
+                unsigned r0, r1, r2;
+                rowsum(y, ring[k], r0, r1, r2);                                      // (rows at and past yend: a re-read row, sums unused)
+                fetch(SLOW_T, y + D < ycl ? y + D : ycl, ring[k]);
+                if (y < yend) {
+                    c0 += r0; c1 += r1; c2 += r2;
+                    if (y >= ys_n) { n0 += r0; n1 += r1; n2 += r2; }
+                    if (y + 1 == ye_c) {                                           // the current bin is complete
+                        if (valid) {
+                            const int kh = ye_c - ys_c;
+                            float4 o4;
+                            o4.x = pyr_norm(c0, kh, kw, g); o4.y = pyr_norm(c1, kh, kw, g); o4.z = pyr_norm(c2, kh, kw, g); o4.w = 0.f;
+                            pyr_store(out + (oy * g.w + ox), o4);
+                        }
+                        c0 = n0; c1 = n1; c2 = n2; n0 = 0; n1 = 0; n2 = 0;
+                        oy++;
+                        ys_c = ys_n; ye_c = ye_n;
+                        edges(oy + 1, ys_n, ye_n);
+                    }
+                }
+            }
+        }
+    };
+    if (lastf && yend >= a.H) run(std::true_type{}); else run(std::false_type{});
+}
+
+__global__ __launch_bounds__(192) void k_pyramid_fine(const uint8_t* __restrict__ frames, PyrFineArgs a, const uint32_t* __restrict__ tab,
+                                                      PyrPx* __restrict__ pyr) {
+    const int lane = threadIdx.x & 63, lvl = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (lvl >= a.nlev) return;
+    const int band = blockIdx.x, strip = blockIdx.z, f = a.f0 + blockIdx.y;
+    const uint32_t* own = tab + a.own0;
+    const uint32_t cb = own[lvl * a.n_bands + band], rb = own[3 * a.n_bands + lvl * a.n_strips + strip];
+    const int ox_lo = __builtin_amdgcn_readfirstlane((int)(cb & 0xFFFF)), ox_hi = __builtin_amdgcn_readfirstlane((int)(cb >> 16));
+    const int oy_lo = __builtin_amdgcn_readfirstlane((int)(rb & 0xFFFF)), oy_hi = __builtin_amdgcn_readfirstlane((int)(rb >> 16));
+    const bool pad_wave = band == 0 && strip == 0;
+    if (lvl == 0) { if (a.g[0].kwmax * 3 + 3 > 16) pyr_fine_wave<true>(frames, a, a.g[0], tab, pyr, f, ox_lo, ox_hi, oy_lo, oy_hi, lane, pad_wave); else pyr_fine_wave<false>(frames, a, a.g[0], tab, pyr, f, ox_lo, ox_hi, oy_lo, oy_hi, lane, pad_wave); }
+    else if (lvl == 1) { if (a.g[1].kwmax * 3 + 3 > 16) pyr_fine_wave<true>(frames, a, a.g[1], tab, pyr, f, ox_lo, ox_hi, oy_lo, oy_hi, lane, pad_wave); else pyr_fine_wave<false>(frames, a, a.g[1], tab, pyr, f, ox_lo, ox_hi, oy_lo, oy_hi, lane, pad_wave); }
+    else { if (a.g[2].kwmax * 3 + 3 > 16) pyr_fine_wave<true>(frames, a, a.g[2], tab, pyr, f, ox_lo, ox_hi, oy_lo, oy_hi, lane, pad_wave); else pyr_fine_wave<false>(frames, a, a.g[2], tab, pyr, f, ox_lo, ox_hi, oy_lo, oy_hi, lane, pad_wave); }
+}
+
 // ---- fused PNet --------------------------------------------------------------------------------------
 
 // A-operand k offsets.  k = 4s+kq walks (tap, channel) of a [pixel][C] LDS tile whose rows are E floats
@@ -1509,6 +1645,44 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
     const bool new_shape = (c->pyr_tab == nullptr || c->pyr_tab_H != H || c->pyr_tab_W != W);
     TRL_CHECK(fill_args(c, n, H, W, a, new_shape ? &tab : nullptr));
     if (new_shape) {   // bin-edge tables depend on (H, W) only: built once per frame shape
+        // k_pyramid_fine: which output columns / rows of the (up to three) finest levels belong to which source tile -- those whose
+        // bins START in it.  A band must not own more than 64 columns of any level (one wave = one level's columns of the band).
+        c->pyr_fine.nlev = 0;
+        int nfine = 0;
+        while (nfine < 3 && nfine < a.L && a.lv[nfine].mode == 0 && a.lv[nfine].h <= H && a.lv[nfine].w <= W) nfine++;
+        if (nfine >= 2) {
+            static const int strip_env = getenv("TRL_PYR_FINE_STRIP") ? atoi(getenv("TRL_PYR_FINE_STRIP")) : 0;   // tuning: source rows per tile
+            const int strip_rows = strip_env >= 8 ? strip_env : 24;
+            int band_cols = (int)(62.0 * W / a.lv[0].w);
+            std::vector<uint32_t> own;
+            for (; band_cols >= 16; band_cols--) {
+                const int nb = (W + band_cols - 1) / band_cols, ns = (H + strip_rows - 1) / strip_rows;
+                own.assign((size_t)3 * nb + (size_t)3 * ns, 0u);
+                bool ok = true;
+                for (int l = 0; l < nfine && ok; l++) {
+                    const PLevel& g = a.lv[l];
+                    int o = 0;
+                    for (int b = 0; b < nb; b++) {                   // columns: bin starts are non-decreasing in ox
+                        const int lo = o;
+                        while (o < g.w && (int)(tab[g.xtab0 + o] & 0xFFFF) < (b + 1) * band_cols) o++;
+                        if (o - lo > 64) { ok = false; break; }
+                        own[(size_t)l * nb + b] = (uint32_t)lo | ((uint32_t)o << 16);
+                    }
+                    o = 0;
+                    for (int t = 0; t < ns; t++) {
+                        const int lo = o;
+                        while (o < g.h && (int)(tab[g.ytab0 + o] & 0xFFFF) < (t + 1) * strip_rows) o++;
+                        own[(size_t)3 * nb + (size_t)l * ns + t] = (uint32_t)lo | ((uint32_t)o << 16);
+                    }
+                }
+                if (ok) {
+                    c->pyr_fine.nlev = nfine; c->pyr_fine.own0 = (int)tab.size(); c->pyr_fine.band_cols = band_cols; c->pyr_fine.strip_rows = strip_rows;
+                    c->pyr_fine.n_bands = nb; c->pyr_fine.n_strips = ns;
+                    tab.insert(tab.end(), own.begin(), own.end());
+                    break;
+                }
+            }
+        }
         TRL_HIP(hipStreamSynchronize(s));
         if (c->pyr_tab) TRL_HIP(hipFree(c->pyr_tab));
         c->pyr_tab = nullptr;
@@ -1574,6 +1748,18 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
         if (fine_on) TRL_CHECK(stream_group(true, fbands_env > 0 ? fbands_env : 8));
     }
     const bool stream_ok = true;
+    // the finest levels in one pass over the source (TRL_PYR_FINE=0: the per-level kernels)
+    static const bool fine_off = getenv("TRL_PYR_FINE") && atoi(getenv("TRL_PYR_FINE")) == 0;
+    if (!fine_off && c->pyr_fine.nlev >= 2 && n <= 65535 && c->pyr_fine.n_strips <= 65535) {
+        PyrFineArgs fa;
+        fa.H = H; fa.W = W; fa.n_frames = n; fa.f0 = 0; fa.pyr_stride = a.pyr_stride;
+        fa.nlev = c->pyr_fine.nlev; fa.band_cols = c->pyr_fine.band_cols; fa.strip_rows = c->pyr_fine.strip_rows;
+        fa.n_bands = c->pyr_fine.n_bands; fa.n_strips = c->pyr_fine.n_strips; fa.own0 = c->pyr_fine.own0;
+        for (int l = 0; l < 3; l++) fa.g[l] = a.lv[l < fa.nlev ? l : 0];
+        k_pyramid_fine<<<dim3(fa.n_bands, n, fa.n_strips), 192, 0, s>>>(d_frames, fa, c->pyr_tab, pyr);
+        TRL_LAUNCH_CHECK();
+        for (int l = 0; l < fa.nlev; l++) streamed[l] = true;
+    }
     for (int f0 = 0; f0 < n; f0 += chunk) {
         const int nf = (n - f0 < chunk) ? n - f0 : chunk;
         for (int l = 0; l < a.L; l++) {
