@@ -14,9 +14,9 @@ as a child, BEFORE anything here touches the GPU -- and exits with the child's c
   --config {0,1,2,4}      : which BASELINE.json configs[] entry the workload is (1 = headline, default).
   --ingest nv12           : supplementary leg: host NV12 -> pinned H2D -> BGR on the device -> the same path.
   --embed-group G         : the decoupled embedder embeds the crops of G consecutive steps in ONE InceptionResnetV1 call on its own context
-                            (default 4 = 1024 faces per call; 1 = inside each step's call).  Results are bit-identical for any G: the
-                            embedder's ~100 small dependent launches amortise over more faces (2.22 ms per 256 faces at 256 per call,
-                            1.78 ms = 42.7 % of the f32-MFMA peak at 768, 1.69 ms = 45 % at 1024).
+                            (default 8 = 2048 faces per call; 1 = inside each step's call).  Results are bit-identical for any G: the
+                            embedder's ~100 small dependent launches amortise over more faces (2.16 ms per 256 faces at 256 per call,
+                            1.61 ms = 47 % of the f32-MFMA peak at 1024, 1.37 ms = 55 % at 2048; 12 and 16 gain nothing more).
   --driver single|threads : ONE host thread drives every context through trl_detect_embed_begin / _end (default), or one blocking
                             host thread per context (round 2's scheme; --embed-group then groups per worker).
 Rank 0 prints ONE JSON line.
@@ -184,7 +184,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo to rehearse N>1 on one GPU")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="batches in flight per GPU: each gets its own context, HIP stream and host thread; 1 = strictly sequential")
-    ap.add_argument("--embed-group", type=int, default=4,
+    ap.add_argument("--embed-group", type=int, default=8,
                     help="consecutive steps whose crops the decoupled embedder embeds in ONE InceptionResnetV1 call (trl_detect_crop per "
                          "step into a ring, then one trl_facenet_embed_masked): same bits, ~100 small launches amortised over G x 256 faces")
     ap.add_argument("--driver", default="single", choices=["threads", "single"],

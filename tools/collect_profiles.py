@@ -42,12 +42,12 @@ def main():
     open(os.path.join(DST, f"{tag}_step_timeline_inflight1.txt"), "w").write(summ)
     for name in ("bench_sustained", "bench_config2", "bench_config4", "bench_prelu_general", "bench_prelu_general_inflight1", "bench_ingest_nv12",
                  "bench_gloo2_sharded", "bench_gloo2_streams", "bench_gloo2_streams_nv12", "bench_embed_group3", "bench_config0", "run_config0",
-                 "bench_driver_threads", "bench_embed_group1", "bench_inflight1_group1", "bench_inflight1_group1_nocarry"):
+                 "bench_driver_threads", "bench_embed_group1", "bench_embed_group4", "bench_inflight1_group1", "bench_inflight1_group1_nocarry"):
         src = os.path.join(SRC, name + ".json")
         if os.path.exists(src) and os.path.getsize(src) > 0:
             shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
     for sub, out in (("stats_c2", "config2_kernel_stats_inflight1.csv"), ("stats_c4", "config4_kernel_stats_inflight1.csv"),
-                     ("stats_fn1024", "facenet_1024faces_kernel_stats.csv")):
+                     ("stats_fn2048", "facenet_2048faces_kernel_stats.csv")):
         src = os.path.join(SRC, sub, "s_kernel_stats.csv")
         if os.path.exists(src):
             shutil.copy(src, os.path.join(DST, f"{tag}_{out}"))

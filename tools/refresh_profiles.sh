@@ -20,6 +20,7 @@ timeout -k 10 300 python bench.py --config 0 --steps 20 --warmup 5 > $O/bench_co
 timeout -k 10 300 python tools/run_wall_time.py $O/run_config0.json > $O/run_config0.log 2>&1
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --driver threads --embed-group 1 > $O/bench_driver_threads.json 2> $O/bench_driver_threads.err
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --embed-group 1 > $O/bench_embed_group1.json 2> $O/bench_embed_group1.err
+timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --embed-group 4 > $O/bench_embed_group4.json 2> $O/bench_embed_group4.err
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --in-flight 1 --embed-group 1 > $O/bench_inflight1_group1.json 2> $O/bench_inflight1_group1.err
 TRL_PNET_RUN=1 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --in-flight 1 --embed-group 1 > $O/bench_inflight1_group1_nocarry.json 2> $O/bench_inflight1_group1_nocarry.err
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --mode streams --ingest nv12 --steps 6 $B > $O/bench_gloo2_streams_nv12.json 2> $O/bench_gloo2_streams_nv12.err
@@ -39,8 +40,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS
 echo "pmc done"
 timeout -k 10 200 python tools/time_facenet.py 20 256 > $O/facenet_ms.txt 2>&1
 timeout -k 10 200 python tools/time_facenet.py 10 768 >> $O/facenet_ms.txt 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_fn1024 -o s -f csv -- python3 tools/time_facenet.py 5 1024 > $O/stats_fn1024.log 2>&1
 timeout -k 10 200 python tools/time_facenet.py 8 1024 >> $O/facenet_ms.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_fn2048 -o s -f csv -- python3 tools/time_facenet.py 4 2048 > $O/stats_fn2048.log 2>&1
+timeout -k 10 200 python tools/time_facenet.py 6 2048 >> $O/facenet_ms.txt 2>&1
 timeout -k 10 200 python tools/fn_stamps.py 2 5 16 58 60 61 2>&1 | grep -E "launch|fn stamps" > $O/facenet_stamps.txt
 echo "facenet done"
 # where the waves of the fused PNet kernel spend their time (DBG instantiation: shader clocks per phase and barrier), its phase
