@@ -8,7 +8,7 @@ from truely_amd.pipeline import detect_embed_overlapped
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-G = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 blob = truely_amd.weights.synthetic_blob(0)
 fr = torch.from_numpy(truely_amd.synthetic.synthetic_frames(n, 720, 1280, seed=0)).cuda()
