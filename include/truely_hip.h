@@ -29,14 +29,15 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 6
+#define TRL_ABI_VERSION 7
 
 typedef enum {
     TRL_OK = 0,
     TRL_ERR_INVALID = -1,   /* bad argument / shape */
     TRL_ERR_HIP = -2,       /* HIP runtime error (message has hipGetErrorString) */
     TRL_ERR_WEIGHTS = -3,   /* blob malformed or tensor missing */
-    TRL_ERR_CAPACITY = -4,  /* a candidate list exceeded its configured capacity */
+    TRL_ERR_CAPACITY = -4,  /* (ABI <= 6: a candidate list exceeded its configured capacity.  Since ABI 7 no input can
+                             *  produce it: lists grow to what the content needs, as detect_face() has no limit) */
     TRL_ERR_STATE = -5      /* call order (e.g. no weights loaded) */
 } trl_status;
 
@@ -49,8 +50,11 @@ typedef struct {
     int    min_face_size;   /* 20 */
     float  thr0, thr1, thr2;/* 0.6 0.7 0.7 */
     double factor;          /* 0.709 */
-    int    cap_level;       /* max PNet cells passing thr0 per (frame, pyramid level)   [4096] */
-    int    cap_frame;       /* max candidates per frame entering R-Net                   [4096] */
+    int    cap_level;       /* START capacity of the per-(frame, pyramid level) candidate lists   [2048] */
+    int    cap_frame;       /* START capacity of the per-frame box lists of stages 1-3           [2048]
+                             * Lists are never longer than the geometry allows (a level has oh x ow cells) and grow with
+                             * the content: a call whose frames need more is re-run internally with larger lists (and
+                             * sorted / suppressed through a global-memory tier beyond the LDS tier), never refused. */
     int    max_faces;       /* max boxes returned per frame by trl_mtcnn_detect          [64]   */
     int    pnet_mode;       /* 0 = fused PNet kernel, 1 = generic layer path (validation) */
     int    embed_mode;      /* 0 = reference: 80x80 INTER_LINEAR crop, BGR, /255 (model.py:41,57-58)  [default]
@@ -120,8 +124,9 @@ int  trl_facenet_embed_masked(trl_ctx* ctx, const float* d_faces, const uint8_t*
 /* The same two calls split into "queue" and "finish", so ONE host thread can keep several contexts (one per batch in flight, or
  * one per GPU) busy without a thread per context: *_begin validates, queues every kernel of the call on `stream` and returns
  * without synchronising; trl_detect_embed_end is the call's one host synchronisation, checks the candidate capacities and -- rarely,
- * when an optimistic R-/O-Net batch capacity was too small -- re-runs the call before returning.  Outputs are valid after _end.  A
- * context holds at most one call in flight (TRL_ERR_STATE otherwise); the buffers must stay alive until _end returns.
+ * when a candidate list or an optimistic R-/O-Net batch capacity was too small for the content -- re-runs the call with larger
+ * ones before returning.  Outputs are valid after _end.  A
+ * context holds at most one call in flight (TRL_ERR_STATE from every entry point that would touch its workspaces meanwhile); the buffers must stay alive until _end returns.
  * server/model.py:42-59 is strictly one frame at a time; this is the batched, overlapped form of the same two library calls. */
 int  trl_detect_embed_begin(trl_ctx* ctx, const uint8_t* d_frames, int n, int H, int W,
                             float* d_box, float* d_prob, int32_t* d_rect, uint8_t* d_valid, float* d_emb, void* stream);
@@ -156,6 +161,14 @@ int  trl_debug_level_counts(trl_ctx* ctx, int frame, int32_t* h_cand, int32_t* h
  * rows of 40 bytes {x1,y1,x2,y2,score,r0,r1,r2,r3 : f32; cell : i32}, cell = y*ow + x of the PNet output map.  With
  * thr0 = 0 every cell is a candidate, so this reads the fused kernel's own probability / regression maps. */
 int  trl_debug_level_cands(trl_ctx* ctx, int frame, int level, void* h_rows, int max_rows, int* n_out);
+/* test hook: LDS tiers of the sort + NMS kernels in candidates per list (0 keeps a value; multiples of 4 in [16, 3072]; defaults
+ * 512 / 2048).  Lists longer than `full_tier` are sorted and suppressed in global memory (the spill tier); lowering the tiers
+ * lets small inputs reach it.  Results never depend on the tiers. (ABI v7) */
+int  trl_debug_nms_tiers(trl_ctx* ctx, int small_tier, int full_tier);
+/* candidate-list statistics of the last call: h_out8 = {attempts, lists that took the spill tier, spill bytes used, spill bytes
+ * available, rows per frame of the stage lists, record slots per frame over all levels, largest per-level candidate count,
+ * largest per-frame stage-1 total} (ABI v7) */
+int  trl_debug_list_stats(trl_ctx* ctx, long long* h_out8);
 /* test hook: the R-/O-Net launches are sized by optimistic per-frame candidate capacities; set them (<= 0 keeps a value) and read
  * how many attempts the last call took (a too-small capacity makes the call re-run itself with a larger one) */
 int  trl_debug_batch_capacity(trl_ctx* ctx, float t2_per_frame, float t3_per_frame, int* last_attempts);

@@ -141,12 +141,12 @@ class Oracle:
         return out
 
     # ---- cascade ----
-    def detect(self, frame, max_out=64, trace=False):
+    def detect(self, frame, max_out=64, trace=False, max_trace=8192):
         frame = np.ascontiguousarray(frame, np.uint8); H, W = frame.shape[:2]
         boxes = np.zeros((max_out, 4), np.float32); probs = np.zeros((max_out,), np.float32)
         tr = None; bufs = None
         if trace:
-            mb = 8192
+            mb = int(max_trace)
             bufs = [np.zeros((mb, 5), np.float32) for _ in range(3)] + [np.zeros((mb, 10), np.float32)]
             tr = Trace(); tr.max_boxes = mb
             tr.boxes1, tr.boxes2, tr.boxes3, tr.points3 = (_p(b) for b in bufs)
@@ -155,6 +155,8 @@ class Oracle:
         k = min(n, max_out)
         res = (boxes[:k].copy(), probs[:k].copy()) if n > 0 else (None, None)
         if trace:
+            if max(tr.n1, tr.n2, tr.n3) > mb:
+                raise ValueError(f"trace buffers hold {mb} boxes per stage, the frame produced {tr.n1}/{tr.n2}/{tr.n3}: pass max_trace")
             t = {"n_scales": tr.n_scales, "n_cand_scale": list(tr.n_cand_scale[:tr.n_scales]),
                  "n_keep_scale": list(tr.n_keep_scale[:tr.n_scales]),
                  "boxes1": bufs[0][:tr.n1].copy(), "boxes2": bufs[1][:tr.n2].copy(),

@@ -89,14 +89,19 @@ def test_analyze_video_batching_invariant(engine):
     assert torch.equal(a["emb"], b["emb"]) and torch.equal(a["valid"], b["valid"]) and torch.equal(a["sims"], b["sims"])
 
 
-def test_capacity_overflow_is_an_error(blob):
+def test_candidate_lists_grow_instead_of_failing(blob, engine):
+    """detect_face() has no candidate limit (server/model.py:47 never refuses a frame), so a context whose START capacities
+    are far too small for the content re-runs the call with larger lists and delivers what a roomy context delivers."""
     from truely_amd.engine import Engine
-    from truely_amd._lib import TrlError
     small = Engine(blob, cap_level=64, cap_frame=64)
-    fr = truely_amd.synthetic.synthetic_frames(1, 720, 1280, seed=0)
-    with pytest.raises(TrlError) as e:
-        small.detect_embed(fr)
-    assert e.value.status == -4 and "overflow" in str(e.value)
+    fr = truely_amd.synthetic.synthetic_frames(2, 720, 1280, seed=0)
+    got, ref = small.detect_embed(fr), engine.detect_embed(fr)
+    st = small.list_stats()
+    assert st["attempts"] >= 2 and st["max_level_count"] > 64
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        assert torch.equal(got[k], ref[k]), k
+    small.detect_embed(fr)
+    assert small.list_stats()["attempts"] == 1           # the capacities follow the content: the next call fits at once
 
 
 def test_bad_arguments_are_rejected(engine):
@@ -504,23 +509,50 @@ def test_large_embedder_batches_cross_kernel_families(engine, oracle):
 
 
 def test_overlapped_pipeline_recovers_from_a_failed_call(blob):
-    """A crowded batch overflows a candidate list (TRL_ERR_CAPACITY: an error, never a truncation) in the middle of an overlapped
-    run: the exception propagates, every engine's queued call is finished on the way out, and the same engines work again."""
+    """A call fails in the middle of an overlapped run (a batch the library rejects: frames below the 12x12 PNet field): the
+    exception propagates, every engine's queued call is finished on the way out, and the same engines work again.  (Crowded
+    content is no failure any more: the noisy batch, far beyond the tiny start capacities, simply re-runs with larger lists.)"""
     from truely_amd._lib import TrlError
     from truely_amd.engine import Engine
     from truely_amd.pipeline import detect_embed_overlapped
     engs = [Engine(blob, cap_level=64, cap_frame=64) for _ in range(2)]
     good = truely_amd.synthetic.synthetic_frames(2, 97, 131, seed=1)
-    noisy = np.random.default_rng(0).integers(0, 256, (2, 180, 320, 3), dtype=np.uint8)   # far more than 64 candidates per level
+    noisy = np.random.default_rng(0).integers(0, 256, (2, 97, 131, 3), dtype=np.uint8)   # far more than 64 candidates per level
+    bad = np.zeros((2, 8, 8, 3), np.uint8)
     for G in (1, 2):
         with pytest.raises(TrlError) as ei:
-            detect_embed_overlapped(engs, [good, good, noisy, good, good], embed_group=G)
-        assert ei.value.status == -4
-        outs = detect_embed_overlapped(engs, [good, good, good], embed_group=G)          # no "call in flight" left behind
+            detect_embed_overlapped(engs, [good, good, bad, good, good], embed_group=G)
+        assert ei.value.status == -1
+        outs = detect_embed_overlapped(engs, [good, noisy, good], embed_group=G)          # no "call in flight" left behind
         assert len(outs) == 3
+        assert max(e.list_stats()["attempts"] for e in engs) >= 1
     ref = Engine(blob).detect_embed(good)
     outs = detect_embed_overlapped([Engine(blob), Engine(blob)], [good, good], embed_group=2)
     assert torch.equal(outs[1]["emb"], ref["emb"])
+    ref_n = Engine(blob).detect_embed(noisy)
+    outs = detect_embed_overlapped(engs, [good, noisy, good], embed_group=2)
+    for k in ("box", "rect", "valid", "emb"):
+        assert torch.equal(outs[1][k], ref_n[k]), k
+
+
+def test_entry_points_refuse_a_context_with_a_call_in_flight(blob):
+    """ABI: a context holds ONE queued call; every entry point that would reset or grow its workspaces meanwhile returns
+    TRL_ERR_STATE instead of corrupting that call (trl_detect_embed_begin .. _end)."""
+    from truely_amd._lib import TrlError
+    from truely_amd.engine import Engine
+    eng = Engine(blob)
+    fr = truely_amd.synthetic.synthetic_frames(2, 97, 131, seed=1)
+    ref = eng.detect_embed(fr)
+    eng.detect_embed_begin(fr)
+    for call in (lambda: eng.detect_embed(fr), lambda: eng.mtcnn_detect(fr), lambda: eng.facenet_embed(torch.zeros(1, 80, 80, 3)),
+                 lambda: eng.embed_faces(torch.zeros(1, 80, 80, 3), torch.ones(1, dtype=torch.uint8)), lambda: eng.stage_boxes(1, 0),
+                 lambda: eng.poison_workspaces(0xFF), lambda: eng.pyramid_level(fr[0], 0)):
+        with pytest.raises(TrlError) as ei:
+            call()
+        assert ei.value.status == -5
+    out = eng.detect_embed_end()
+    for k in ("box", "rect", "valid", "emb"):
+        assert torch.equal(out[k], ref[k]), k
 
 
 def test_batches_beyond_16k_frames(blob):

@@ -186,10 +186,7 @@ def test_config4_as_stated_4k_twelve_levels_fp16_batch(blob):
 @pytest.mark.parametrize("H,W,faces,seed", [(1080, 1920, -1, 31), (2160, 3840, 1, 32)])
 def test_large_frames_against_oracle(engine, blob, oracle, H, W, faces, seed):
     """configs[2] (1080p, 3-5 faces) and configs[4] (4K, min_face_size=20 -> 14 pyramid levels), fp32 path."""
-    if H > 1080:   # a 4K frame has ~3x the candidates of the default list capacity: use the largest lists
-        from truely_amd.engine import Engine
-        engine = Engine(blob, cap_level=3072, cap_frame=3072)
-    fr = _frame(H, W, faces, seed)
+    fr = _frame(H, W, faces, seed)    # (the 4K frame has ~3x the candidates of the default START capacity: the lists grow)
     engine.detect_embed(fr)          # sizes the workspaces ...
     engine.poison_workspaces(0xFF)   # ... which are then NaN-filled, like the LDS: see test_results_do_not_depend_on_stale_memory
     out = engine.detect_embed(fr)
@@ -201,6 +198,53 @@ def test_large_frames_against_oracle(engine, blob, oracle, H, W, faces, seed):
         assert np.array_equal(engine.stage_boxes(s, 0), tr[f"boxes{s}"])
     ref = oracle.detect_embed(fr)
     assert np.array_equal(out["rect"].cpu().numpy(), ref["rect"]) and np.array_equal(out["emb"].cpu().numpy(), ref["emb"])
+
+
+def _check_crowded(eng, orc, fr):
+    """One frame, every record of the cascade against the oracle (lists of any length), then the delivered outputs."""
+    eng.poison_workspaces(0xFF)
+    out = eng.detect_embed(fr)
+    _b, _p, tr = orc.detect(fr[0], trace=True, max_trace=1 << 20)
+    cand, keep = eng.level_counts(0)
+    assert cand == tr["n_cand_scale"] and keep == tr["n_keep_scale"], (cand, tr["n_cand_scale"])
+    for s in (1, 2, 3):
+        got = eng.stage_boxes(s, 0)
+        assert got.shape == tr[f"boxes{s}"].shape and np.array_equal(got, tr[f"boxes{s}"]), s
+    ref = orc.detect_embed(fr)
+    for k in ("box", "prob", "rect", "valid", "emb"):
+        assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+    return tr, eng.list_stats()
+
+
+def test_default_engine_on_a_720p_uniform_noise_frame(blob, oracle):
+    """Content that defeats every fixed capacity: uniform noise at 720p fires ~4,800 PNet cells at the finest level alone, ~5,600
+    boxes enter R-Net and ~2,500 survive O-Net.  The reference (`mtcnn.detect`, server/model.py:47) returns boxes for ANY frame;
+    a DEFAULT context does too: lists grow (re-run), the long ones are sorted / suppressed in global memory, results = oracle."""
+    from truely_amd.engine import Engine
+    eng = Engine(blob)
+    fr = np.random.default_rng(1).integers(0, 256, (1, 720, 1280, 3), dtype=np.uint8)
+    tr, st = _check_crowded(eng, oracle, fr)
+    assert max(tr["n_cand_scale"]) > 2048 and len(tr["boxes1"]) > 2048 and len(tr["boxes3"]) > 2048   # every stage beyond the LDS tier
+    assert st["attempts"] >= 2 and st["spill_lists"] >= 4, st
+    _check_crowded(eng, oracle, fr)
+    assert eng.list_stats()["attempts"] == 1              # the capacities now follow the content
+    calm = truely_amd.synthetic.synthetic_frames(1, 720, 1280, seed=0)
+    _check_crowded(eng, oracle, calm)                     # ... and a calm frame on the grown context is unchanged
+
+
+def test_default_engine_on_a_4k_frame_at_a_low_pnet_threshold(blob):
+    """A 4K frame (min_face_size 20: 14 levels, 739 k PNet cells at the finest) at thr0 = 0.55: ~30 k candidates at the finest
+    level alone, far past the LDS tier -- default capacities, results = oracle.  (At thr0 = 0.3 this frame fires 736,593 of the
+    739,312 cells of level 0 and ~1 M boxes enter R-Net: the device path runs it -- tools/crowded_timing.py, DESIGN.md -- but the
+    CPU oracle needs the better part of an hour for it, so the parity case sits at the threshold the oracle finishes in seconds.)"""
+    from oracle.oracle import Oracle
+    from truely_amd.engine import Engine
+    eng = Engine(blob, thresholds=(0.55, 0.7, 0.7))
+    orc = Oracle(blob)
+    orc.params.thr0 = 0.55
+    fr = _frame(2160, 3840, 1, 32)
+    tr, st = _check_crowded(eng, orc, fr)
+    assert tr["n_cand_scale"][0] > 10000 and st["spill_lists"] >= 1, (tr["n_cand_scale"], st)
 
 
 def test_frames_without_candidates(engine, oracle):

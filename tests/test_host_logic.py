@@ -29,7 +29,7 @@ def test_header_symbols_exported_by_library():
 
 def test_library_loads_and_reports_abi():
     lib = _lib.load()
-    assert lib.trl_abi_version() == 6
+    assert lib.trl_abi_version() == 7
     cfg = _lib.TrlConfig()
     assert lib.trl_default_config(ctypes.byref(cfg)) == 0
     assert (cfg.min_face_size, round(cfg.thr0, 3), round(cfg.thr1, 3), round(cfg.thr2, 3), cfg.factor) == (20, 0.6, 0.7, 0.7, 0.709)

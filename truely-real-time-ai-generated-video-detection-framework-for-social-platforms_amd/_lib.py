@@ -47,6 +47,8 @@ _SIGNATURES = {
     "trl_debug_level_counts": (C.c_int, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
     "trl_debug_level_cands": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "trl_debug_batch_capacity": (C.c_int, [_vp, _f, _f, C.POINTER(_i)]),
+    "trl_debug_nms_tiers": (C.c_int, [_vp, _i, _i]),
+    "trl_debug_list_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
     "trl_debug_poison": (C.c_int, [_vp, _i]),
     "trl_debug_pyramid_level": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),
     "trl_debug_pnet_level": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),
@@ -82,7 +84,7 @@ def load(path: str | None = None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.trl_abi_version() != 6:
+    if lib.trl_abi_version() != 7:
         raise ImportError("libtruely_hip ABI mismatch")
     _lib = lib
     return lib

@@ -37,10 +37,10 @@ int trl_default_config(trl_config* cfg) {
 
 int trl_create(const trl_config* cfg, trl_ctx** out) {
     if (!cfg || !out) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
-    if (cfg->cap_level < 64 || cfg->cap_level > 3072 || cfg->cap_frame < 64 || cfg->cap_frame > 3072 || (cfg->cap_level & 3) ||
+    if (cfg->cap_level < 64 || cfg->cap_level > (1 << 24) || cfg->cap_frame < 64 || cfg->cap_frame > (1 << 24) || (cfg->cap_level & 3) ||
         (cfg->cap_frame & 3) || cfg->min_face_size < 12 || cfg->max_faces < 1 || !(cfg->factor > 0.1 && cfg->factor < 0.99) || cfg->embed_mode < 0 || cfg->embed_mode > 3 ||
         cfg->embed_precision < 0 || cfg->embed_precision > 2) {
-        trl_set_error("bad trl_config (capacities must be multiples of 4 in [64,3072], min_face_size >= 12)");
+        trl_set_error("bad trl_config (list start capacities must be multiples of 4 in [64, 2^24], min_face_size >= 12)");
         return TRL_ERR_INVALID;
     }
     TRL_HIP(hipSetDevice(cfg->device));
@@ -50,13 +50,13 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
     // TRL_PNET_CLOCK additionally selects the DBG instantiation with per-phase wave clocks
     c->pnet_prof = getenv("TRL_PNET_CLOCK") != nullptr;
     if (hipMalloc((void**)&c->pnet_clk, 8 * 40) != hipSuccess || hipMemset(c->pnet_clk, 0, 8 * 40) != hipSuccess || hipMemset(c->pnet_clk, 0xFF, 8) != hipSuccess ||
-        hipMalloc((void**)&c->pnet_cursor, 64) != hipSuccess || hipHostMalloc((void**)&c->h_pinned, 256) != hipSuccess ||
+        hipMalloc((void**)&c->pnet_cursor, 64) != hipSuccess || hipHostMalloc((void**)&c->h_pinned, 1024) != hipSuccess ||
         hipEventCreate(&c->ev_call0) != hipSuccess || hipEventCreate(&c->ev_call1) != hipSuccess) {
         trl_set_error("context allocation failed: %s", hipGetErrorString(hipGetLastError()));
         trl_destroy(c);                      // frees whatever was created
         return TRL_ERR_HIP;
     }
-    memset(c->h_pinned, 0, 256);
+    memset(c->h_pinned, 0, 1024);
     *out = c;
     return TRL_OK;
 }
@@ -64,7 +64,8 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
 int trl_destroy(trl_ctx* c) {
     if (!c) return TRL_OK;
     (void)hipSetDevice(c->cfg.device);
-    (void)hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();            // (also ends a call that was queued and never finished: its kernels are done)
+    c->pend.active = false;
     for (auto& kv : c->W) if (kv.second.pt) (void)hipFree(kv.second.pt);
     if (c->wdev) (void)hipFree(c->wdev);
     if (c->arena.base) (void)hipFree(c->arena.base);
@@ -289,8 +290,21 @@ extern "C" int trl_load_weights(trl_ctx* c, const void* blob, size_t nbytes) {
 }
 
 // ---- hot path ---------------------------------------------------------------------------------------
+// Every attempt raises the one capacity it found too small to what the content needs (level lists -> frame lists -> R-Net batch
+// -> O-Net batch, plus the spill workspace), so a call converges in at most a handful; the bound only guards against a bug.
+enum { TRL_MAX_ATTEMPTS = 12 };
+
+// A context holds at most one queued call (trl_detect_embed_begin .. _end); anything else that touches its workspaces meanwhile
+// would corrupt that call silently.
+static int check_idle(trl_ctx* c) {
+    if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
+    if (c->pend.active) { trl_set_error("the context has a call in flight: trl_detect_embed_end() first"); return TRL_ERR_STATE; }
+    return TRL_OK;
+}
+
 static int check_call(trl_ctx* c, const void* frames, int n, int H, int W) {
     if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
+    TRL_CHECK(check_idle(c));
     if (!c->have_weights) { trl_set_error("trl_load_weights has not been called"); return TRL_ERR_STATE; }
     if (!frames || n <= 0 || n > 65535 || H < 12 || W < 12 || H > 16383 || W > 16383) {   // n: grid.y carries the frame index in several kernels
         trl_set_error("bad frame batch n=%d H=%d W=%d (1..65535 frames of 12..16383 px per side)", n, H, W);
@@ -366,7 +380,7 @@ static int mtcnn_detect_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, 
         TRL_CHECK(trl_cascade_check(c, n, &retry));
         c->last_attempts = attempt + 1;
         if (!retry) break;
-        if (attempt >= 3) { trl_set_error("candidate batch capacity did not converge"); return TRL_ERR_STATE; }
+        if (attempt >= TRL_MAX_ATTEMPTS - 1) { trl_set_error("candidate capacities did not converge"); return TRL_ERR_STATE; }
     }
     collect_timings(c);
     return TRL_OK;
@@ -374,6 +388,7 @@ static int mtcnn_detect_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, 
 
 int trl_facenet_embed(trl_ctx* c, const float* d_faces, int n, int h, int w, float* d_emb, void* stream) {
     if (!c || !c->have_weights) { trl_set_error("context without weights"); return TRL_ERR_STATE; }
+    TRL_CHECK(check_idle(c));
     if (!d_faces || !d_emb || n <= 0 || h < 75 || w < 75) { trl_set_error("bad face batch n=%d %dx%d (min 75x75)", n, h, w); return TRL_ERR_INVALID; }
     TRL_HIP(hipSetDevice(c->cfg.device));
     c->scratch.reset();
@@ -438,7 +453,7 @@ static int detect_embed_wait(trl_ctx* c) {
         if ((st = trl_cascade_check(c, c->pend.n, &retry)) != TRL_OK) break;
         c->last_attempts = ++c->pend.attempt;
         if (!retry) break;                            // (a retry re-runs the call with larger R-/O-Net batch capacities)
-        if (c->pend.attempt >= 4) { trl_set_error("candidate batch capacity did not converge"); st = TRL_ERR_STATE; break; }
+        if (c->pend.attempt >= TRL_MAX_ATTEMPTS) { trl_set_error("candidate capacities did not converge"); st = TRL_ERR_STATE; break; }
         if ((st = detect_embed_enqueue(c)) != TRL_OK) break;
     }
     c->pend.active = false;
@@ -478,6 +493,7 @@ int trl_detect_crop(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, fl
 
 int trl_facenet_embed_masked(trl_ctx* c, const float* d_faces, const uint8_t* d_valid, int n, int h, int w, float* d_emb, void* stream) {
     if (!c || !c->have_weights) { trl_set_error("context without weights"); return TRL_ERR_STATE; }
+    TRL_CHECK(check_idle(c));
     if (!d_faces || !d_valid || !d_emb || n <= 0 || h < 75 || w < 75) { trl_set_error("bad face batch n=%d %dx%d (min 75x75)", n, h, w); return TRL_ERR_INVALID; }
     TRL_HIP(hipSetDevice(c->cfg.device));
     c->scratch.reset();
@@ -499,7 +515,8 @@ int trl_drift_score(trl_ctx* c, const float* d_emb, const uint8_t* d_valid, int 
 
 // ---- inspection hooks ----------------------------------------------------------------------------------
 int trl_debug_stage_boxes(trl_ctx* c, int stage, int frame, float* h_boxes, int max_rows, int* n_out) {
-    if (!c || !c->cb.n1 || frame < 0 || frame >= c->cb.n || stage < 1 || stage > 3 || !n_out || (max_rows > 0 && !h_boxes)) {
+    TRL_CHECK(check_idle(c));
+    if (!c->cb.n1 || frame < 0 || frame >= c->cb.n || stage < 1 || stage > 3 || !n_out || (max_rows > 0 && !h_boxes)) {
         trl_set_error("no cascade state");
         return TRL_ERR_STATE;
     }
@@ -510,7 +527,7 @@ int trl_debug_stage_boxes(trl_ctx* c, int stage, int frame, float* h_boxes, int 
     TRL_HIP(hipMemcpy(&k, cnt + frame, 4, hipMemcpyDeviceToHost));
     *n_out = k;
     const int m = k < max_rows ? k : max_rows;
-    if (m > 0) TRL_HIP(hipMemcpy(h_boxes, src + (size_t)frame * c->cfg.cap_frame * 5, (size_t)m * 20, hipMemcpyDeviceToHost));
+    if (m > 0) TRL_HIP(hipMemcpy(h_boxes, src + (size_t)frame * c->cb.capF * 5, (size_t)m * 20, hipMemcpyDeviceToHost));
     return TRL_OK;
 }
 
@@ -524,7 +541,7 @@ __global__ void k_poison_lds(unsigned word, int nwords) {
 // Fills every byte of the activation workspaces with `byte` (0xFF = NaN patterns, 0x7F = huge finite floats): a
 // result that depends on workspace contents left by an earlier call or process shows up as a parity failure.
 int trl_debug_poison(trl_ctx* c, int byte) {
-    if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
+    TRL_CHECK(check_idle(c));
     TRL_HIP(hipSetDevice(c->cfg.device));
     TRL_HIP(hipDeviceSynchronize());
     c->dbg_poison = byte & 0xFF;                 // sticky: blocks allocated later are filled too
@@ -541,7 +558,8 @@ int trl_debug_poison(trl_ctx* c, int byte) {
 }
 
 int trl_debug_level_counts(trl_ctx* c, int frame, int32_t* h_cand, int32_t* h_keep, int* n_levels) {
-    if (!c || !c->cb.lvl_cnt || frame < 0 || frame >= c->cb.n || !h_cand || !h_keep || !n_levels) { trl_set_error("no cascade state"); return TRL_ERR_STATE; }
+    TRL_CHECK(check_idle(c));
+    if (!c->cb.lvl_cnt || frame < 0 || frame >= c->cb.n || !h_cand || !h_keep || !n_levels) { trl_set_error("no cascade state"); return TRL_ERR_STATE; }
     TRL_HIP(hipDeviceSynchronize());
     const int L = c->cb.L;
     TRL_HIP(hipMemcpy(h_cand, c->cb.lvl_cnt + (size_t)frame * L, (size_t)L * 4, hipMemcpyDeviceToHost));
@@ -552,7 +570,8 @@ int trl_debug_level_counts(trl_ctx* c, int frame, int32_t* h_cand, int32_t* h_ke
 
 // Candidate records (generateBoundingBox rows) one (frame, level) of the last call produced, in append order
 int trl_debug_level_cands(trl_ctx* c, int frame, int level, void* h_rows, int max_rows, int* n_out) {
-    if (!c || !c->cb.lvl_cnt || frame < 0 || frame >= c->cb.n || level < 0 || level >= c->cb.L || !h_rows || !n_out) {
+    TRL_CHECK(check_idle(c));
+    if (!c->cb.lvl_cnt || frame < 0 || frame >= c->cb.n || level < 0 || level >= c->cb.L || !n_out || (max_rows > 0 && !h_rows)) {
         trl_set_error("no cascade state");
         return TRL_ERR_STATE;
     }
@@ -560,10 +579,10 @@ int trl_debug_level_cands(trl_ctx* c, int frame, int level, void* h_rows, int ma
     TRL_HIP(hipDeviceSynchronize());
     int32_t k = 0;
     TRL_HIP(hipMemcpy(&k, c->cb.lvl_cnt + (size_t)frame * c->cb.L + level, 4, hipMemcpyDeviceToHost));
-    if (k > c->cfg.cap_level) k = c->cfg.cap_level;
+    if (k > c->cb.lay.capl[level]) k = c->cb.lay.capl[level];
     *n_out = k;
     const int m = k < max_rows ? k : max_rows;
-    if (m > 0) TRL_HIP(hipMemcpy(h_rows, c->cb.lvl_rec + ((size_t)frame * c->cb.L + level) * c->cfg.cap_level, (size_t)m * sizeof(Cand), hipMemcpyDeviceToHost));
+    if (m > 0) TRL_HIP(hipMemcpy(h_rows, c->cb.lvl_rec + (size_t)frame * c->cb.lay.S + c->cb.lay.rec0[level], (size_t)m * sizeof(Cand), hipMemcpyDeviceToHost));
     return TRL_OK;
 }
 
@@ -598,6 +617,7 @@ int trl_debug_pnet_level(trl_ctx* c, const uint8_t* d_frame, int H, int W, int l
 
 int trl_debug_rnet(trl_ctx* c, const float* d_crops, int n, float* d_out, void* stream) {
     if (!c || !c->have_weights || !d_crops || !d_out || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    TRL_CHECK(check_idle(c));
     c->scratch.reset();
     TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * 100 * 1024 + (4u << 20)));
     return trl_run_rnet(c, d_crops, n, d_out, (hipStream_t)stream);
@@ -608,10 +628,10 @@ int trl_debug_rnet(trl_ctx* c, const float* d_crops, int n, float* d_out, void* 
 // x1,y1,x2,y2 (host); d_out: [nb][6] (net = 24) or [nb][16] (net = 48), device.
 int trl_debug_front_net(trl_ctx* c, const uint8_t* d_frame, int H, int W, const float* h_boxes, int nb, int net, float* d_out, void* stream) {
     TRL_CHECK(check_call(c, d_frame, 1, H, W));
-    if (!h_boxes || !d_out || nb <= 0 || nb > c->cfg.cap_frame || (net != 24 && net != 48)) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    if (!h_boxes || !d_out || nb <= 0 || nb > (1 << 20) || (net != 24 && net != 48)) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     TRL_HIP(hipSetDevice(c->cfg.device));
-    const int capF = c->cfg.cap_frame;
+    const int capF = nb;
     Arena& A = c->arena;
     TRL_CHECK(trl_ensure(c, A, (size_t)capF * 32 + (1u << 20)));
     A.reset();
@@ -648,6 +668,7 @@ int trl_debug_front_net(trl_ctx* c, const uint8_t* d_frame, int H, int W, const 
 
 int trl_debug_onet(trl_ctx* c, const float* d_crops, int n, float* d_out, void* stream) {
     if (!c || !c->have_weights || !d_crops || !d_out || n <= 0) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    TRL_CHECK(check_idle(c));
     c->scratch.reset();
     TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * 640 * 1024 + (4u << 20)));
     return trl_run_onet(c, d_crops, n, d_out, (hipStream_t)stream);
@@ -665,6 +686,33 @@ int trl_debug_crop_aligned(trl_ctx* c, const uint8_t* d_frames, int n, int H, in
 }
 // test hook: set the optimistic R-/O-Net batch capacities (candidates per frame) the next call starts from, and read back how
 // many attempts the last call needed (> 1: a capacity was too small and the call was re-run with a larger one)
+// test hook: the LDS tiers of the sort + NMS kernels (candidates per list; 0 keeps a value).  Lists longer than `full` take the
+// spill tier (global memory): lowering it makes small test inputs exercise that tier.  Results never depend on the tiers.
+int trl_debug_nms_tiers(trl_ctx* c, int small_tier, int full_tier) {
+    TRL_CHECK(check_idle(c));
+    if ((small_tier && (small_tier < 16 || small_tier > 3072 || (small_tier & 3))) || (full_tier && (full_tier < 16 || full_tier > 3072 || (full_tier & 3)))) {
+        trl_set_error("tiers must be multiples of 4 in [16, 3072]");
+        return TRL_ERR_INVALID;
+    }
+    if (small_tier) c->nms_small = small_tier;
+    if (full_tier) c->nms_full = full_tier;
+    return TRL_OK;
+}
+// What the candidate lists of the last call looked like: h_out8 = {attempts, lists that took the spill tier, spill bytes used,
+// spill bytes available, per-frame list capacity, record slots per frame (all levels), largest per-level count, largest per-frame
+// stage-1 total}
+int trl_debug_list_stats(trl_ctx* c, long long* h_out8) {
+    if (!c || !h_out8) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
+    const int32_t* f = c->h_pinned + 4;
+    unsigned long long used = 0;
+    memcpy(&used, f + 8, 8);
+    int mx = 0;
+    for (int l = 0; l < 32; l++) if (f[16 + l] > mx) mx = f[16 + l];
+    h_out8[0] = c->last_attempts; h_out8[1] = f[10]; h_out8[2] = (long long)used; h_out8[3] = (long long)c->cb.spill_cap;
+    h_out8[4] = c->cb.capF; h_out8[5] = c->cb.lay.S; h_out8[6] = mx; h_out8[7] = f[6];
+    return TRL_OK;
+}
+
 int trl_debug_batch_capacity(trl_ctx* c, float t2_per_frame, float t3_per_frame, int* last_attempts) {
     if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
     if (t2_per_frame > 0.f) c->t2_per_frame = t2_per_frame;

@@ -13,6 +13,7 @@
 // -ffp-contract=off), so boxes / keep masks are bit-identical to the oracle.
 #include "trl_ctx.h"
 #include <stdlib.h>
+#include <string.h>
 
 // R-/O-Net candidates per launch set: one set covers a 256-frame batch's CAPACITY (160 / 48 candidates per frame + 64: 41 k / 12.4 k;
 // 31 k / 8.5 k are live), so no dead second chunk is launched (8 launches x 4.7 us); scratch per chunk = 100 KB / 640 KB per
@@ -57,49 +58,84 @@ __device__ __forceinline__ int next_pow2(int n) {
     return p;
 }
 
+// Does kept box i suppress box j?  MIN_MODE = nms_numpy 'Min' (+1 extents, inter / min(area), keep o <= thr); otherwise torchvision
+// nms (inter / (a_i + a_j - inter) > thr suppresses).  One rounding per operation, in the reference's order.
+template <bool MIN_MODE>
+__device__ __forceinline__ bool nms_suppresses(const float4 bi, const float ai, const float4 bj, const float aj, const float thr) {
+    const float xx1 = bi.x > bj.x ? bi.x : bj.x;
+    const float yy1 = bi.y > bj.y ? bi.y : bj.y;
+    const float xx2 = bi.z < bj.z ? bi.z : bj.z;
+    const float yy2 = bi.w < bj.w ? bi.w : bj.w;
+    if (MIN_MODE) {
+        float w = xx2 - xx1 + 1.f; w = w > 0.f ? w : 0.f;
+        float h = yy2 - yy1 + 1.f; h = h > 0.f ? h : 0.f;
+        const float inter = w * h;
+        const float mn = ai < aj ? ai : aj;
+        const float o = inter / mn;
+        return !(o <= thr);
+    } else {
+        float w = xx2 - xx1; w = w > 0.f ? w : 0.f;
+        float h = yy2 - yy1; h = h > 0.f ? h : 0.f;
+        const float inter = w * h;
+        const float ovr = inter / (ai + aj - inter);
+        return ovr > thr;
+    }
+}
+
 // Greedy NMS over boxes already in descending-score order.  MIN_MODE = facenet_pytorch
 // nms_numpy(..., 'Min') (+1 areas, inter/min(area), keep o <= thr); otherwise torchvision nms
 // (inter/(a_i+a_j-inter) > thr suppresses).  keep[] receives positions in pick order.
+// `preset`: sup[] already holds suppressions by boxes that precede this list (the spill tier's earlier chunks).
+// The list is walked in sub-blocks of 64 boxes: wave 0 resolves a sub-block by itself -- lane = box, the next live box is
+// broadcast with v_readlane, no barrier between the 64 dependent steps -- then every thread applies the sub-block's kept boxes
+// to its share of the later boxes.  Two barriers per 64 boxes instead of one per kept box; a box is kept iff no earlier kept box
+// suppresses it, exactly the sequential rule.
 template <bool MIN_MODE>
-__device__ int block_nms(const float4* box, const float* area, int n, float thr, uint8_t* sup, int* keep, int* nkeep) {
-    for (int t = threadIdx.x; t < n; t += blockDim.x) sup[t] = 0;
+__device__ int block_nms(const float4* box, const float* area, int n, float thr, uint8_t* sup, int* keep, int* nkeep, bool preset = false) {
+    __shared__ unsigned long long kept_s;
+    if (!preset) for (int t = threadIdx.x; t < n; t += blockDim.x) sup[t] = 0;
     if (threadIdx.x == 0) *nkeep = 0;
     __syncthreads();
-    for (int i = 0; i < n; i++) {
-        if (sup[i]) continue;   // block-uniform: sup[i] is final once all earlier kept boxes were applied
-        if (threadIdx.x == 0) { keep[*nkeep] = i; *nkeep = *nkeep + 1; }
-        const float4 bi = box[i];
-        const float ai = area[i];
-        for (int j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+        const int nb = n - b0 < 64 ? n - b0 : 64;
+        if (threadIdx.x < 64) {
+            const bool have = lane < nb;
+            const float4 bm = have ? box[b0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float am = have ? area[b0 + lane] : 0.f;
+            bool dead = !have || sup[b0 + lane];
+            const int base = *nkeep;
+            unsigned long long kept = 0;
+            for (int q = 0; q < nb; q++) {
+                if ((__ballot(dead) >> q) & 1) continue;          // wave-uniform: box q was suppressed (or preset)
+                kept |= 1ull << q;
+                const float4 bq = make_float4(__shfl(bm.x, q), __shfl(bm.y, q), __shfl(bm.z, q), __shfl(bm.w, q));
+                const float aq = __shfl(am, q);
+                if (lane > q && !dead && nms_suppresses<MIN_MODE>(bq, aq, bm, am, thr)) dead = true;
+            }
+            if ((kept >> lane) & 1) keep[base + __popcll(kept & ((1ull << lane) - 1ull))] = b0 + lane;
+            if (lane == 0) { kept_s = kept; *nkeep = base + __popcll(kept); }
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_s;
+        for (int j = b0 + 64 + threadIdx.x; j < n; j += blockDim.x) {
             if (sup[j]) continue;
             const float4 bj = box[j];
-            const float xx1 = bi.x > bj.x ? bi.x : bj.x;
-            const float yy1 = bi.y > bj.y ? bi.y : bj.y;
-            const float xx2 = bi.z < bj.z ? bi.z : bj.z;
-            const float yy2 = bi.w < bj.w ? bi.w : bj.w;
-            if (MIN_MODE) {
-                float w = xx2 - xx1 + 1.f; w = w > 0.f ? w : 0.f;
-                float h = yy2 - yy1 + 1.f; h = h > 0.f ? h : 0.f;
-                const float inter = w * h;
-                const float mn = ai < area[j] ? ai : area[j];
-                const float o = inter / mn;
-                if (!(o <= thr)) sup[j] = 1;
-            } else {
-                float w = xx2 - xx1; w = w > 0.f ? w : 0.f;
-                float h = yy2 - yy1; h = h > 0.f ? h : 0.f;
-                const float inter = w * h;
-                const float ovr = inter / (ai + area[j] - inter);
-                if (ovr > thr) sup[j] = 1;
+            const float aj = area[j];
+            bool s = false;
+            for (unsigned long long m = kept; m; m &= m - 1) {
+                const int q = b0 + __ffsll((long long)m) - 1;
+                s |= nms_suppresses<MIN_MODE>(box[q], area[q], bj, aj, thr);
             }
+            if (s) sup[j] = 1;
         }
         __syncthreads();
     }
-    __syncthreads();
     return *nkeep;
 }
 
-// exclusive scan of 0/1 flags (n <= capacity), 256 threads; returns total, pos[] = output slot
-__device__ int block_compact_positions(const uint8_t* flag, int n, int* pos, int* part /*[257]*/) {
+// exclusive scan of 0/1 flags (n <= capacity); returns total, pos[] = output slot
+__device__ int block_compact_positions(const uint8_t* flag, int n, int* pos, int* part /*[blockDim.x + 1]*/) {
     const int tid = threadIdx.x, T = blockDim.x;
     const int per = (n + T - 1) / T;
     const int b = tid * per, e = (b + per < n) ? b + per : n;
@@ -122,7 +158,7 @@ __device__ int block_compact_positions(const uint8_t* flag, int n, int* pos, int
 struct Smem {   // carve the dynamic LDS for capacity `cap`
     uint64_t* key; uint32_t* id; float4* box; float* area; float* aux; int* keep; int* pos; uint8_t* sup; uint8_t* flg;
     int* part; int* scal;
-    __device__ Smem(unsigned char* base, int cap) {
+    __device__ Smem(unsigned char* base, int cap, int threads = 256) {
         key = (uint64_t*)base;                 // 8
         box = (float4*)(key + cap);            // 16
         id = (uint32_t*)(box + cap);           // 4
@@ -130,13 +166,157 @@ struct Smem {   // carve the dynamic LDS for capacity `cap`
         aux = area + cap;                      // 4
         keep = (int*)(aux + cap);              // 4
         pos = keep + cap;                      // 4
-        part = pos + cap;                      // 260 ints
-        scal = part + 260;                     // 8 ints
+        part = pos + cap;                      // threads + 4 ints
+        scal = part + threads + 4;             // 8 ints
         sup = (uint8_t*)(scal + 8);            // 1
         flg = sup + cap;                       // 1
     }
-    static size_t bytes(int cap) { return (size_t)cap * 46 + 268 * 4 + 64; }
+    static size_t bytes(int cap, int threads = 256) { return (size_t)cap * 46 + (size_t)(threads + 12) * 4 + 64; }
 };
+
+// ---- spill tier: lists longer than the LDS tier ----------------------------------------------------------------------------
+// detect_face() has no candidate limit (torchvision's nms and nms_numpy take any number of boxes), so neither has this cascade:
+// a list that does not fit the LDS tier is sorted and suppressed by the SAME workgroup in global memory --
+//   sort   : the same bitonic network on the same 64-bit keys, compare-exchange distances below the LDS chunk run in LDS,
+//            the longer ones in global memory;
+//   NMS    : greedy suppression in chunks of the sorted order: a chunk is first tested against every box kept from earlier
+//            chunks, then suppressed in LDS like a short list.  A box is kept iff no earlier kept box suppresses it -- the
+//            sequential rule, so the pick order and every keep decision equal the LDS tier's (and the reference's).
+// Workspace comes from a bump pool in the cascade arena (one atomic per list); a pool that runs out raises a flag and the call is
+// re-run with a larger one, like every other capacity (trl_cascade_check).
+struct Spill { char* base; unsigned long long cap; int32_t* flags; };
+enum { FLG_LEVEL = 0, FLG_FRAME = 1, FLG_T2 = 2, FLG_T3 = 3, FLG_T2N = 4, FLG_T3N = 5, FLG_FRAME_MAX = 6, FLG_SPILL = 7,
+       FLG_SPILL_CUR = 8 /* u64 */, FLG_SPILL_LISTS = 10, FLG_LEVEL_MAX = 16 /* [32] */ };
+
+__device__ char* spill_alloc(const Spill& sp, size_t bytes) {   // every thread of the workgroup calls it; uniform result
+    __shared__ unsigned long long off_s;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (threadIdx.x == 0) {
+        off_s = atomicAdd(reinterpret_cast<unsigned long long*>(sp.flags + FLG_SPILL_CUR), (unsigned long long)bytes);
+        atomicAdd(&sp.flags[FLG_SPILL_LISTS], 1);
+        if (off_s + bytes > sp.cap) sp.flags[FLG_SPILL] = 1;      // the cursor keeps counting: the host learns the total need
+    }
+    __syncthreads();
+    const unsigned long long o = off_s;
+    __syncthreads();
+    return o + bytes <= sp.cap ? sp.base + o : nullptr;
+}
+__device__ __forceinline__ int pow2_floor(int n) {
+    int p = 1;
+    while (2 * p <= n) p <<= 1;
+    return p;
+}
+// compare-exchange distances j0, j0/2, .., 1 of merge width k on the LDS-resident chunk [base, base + C) of the list
+__device__ void lds_bitonic_steps(uint64_t* key, uint32_t* id, int C, int base, int k, int j0) {
+    for (int j = j0; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < C; t += blockDim.x) {
+            const int u = t ^ j;
+            if (u > t) {
+                const bool up = (((base + t) & k) == 0);
+                const uint64_t a = key[t], b = key[u];
+                if ((a > b) == up) {
+                    key[t] = b; key[u] = a;
+                    const uint32_t ia = id[t]; id[t] = id[u]; id[u] = ia;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+// ascending sort of gk[0..P) (P a power of two, padded with ~0 keys) with payload gi, by one workgroup; lk / li: LDS for C entries
+__device__ void big_bitonic(uint64_t* gk, uint32_t* gi, int P, uint64_t* lk, uint32_t* li, int C) {
+    if (C > P) C = P;
+    for (int base = 0; base < P; base += C) {
+        for (int t = threadIdx.x; t < C; t += blockDim.x) { lk[t] = gk[base + t]; li[t] = gi[base + t]; }
+        __syncthreads();
+        for (int k = 2; k <= C; k <<= 1) lds_bitonic_steps(lk, li, C, base, k, k >> 1);
+        for (int t = threadIdx.x; t < C; t += blockDim.x) { gk[base + t] = lk[t]; gi[base + t] = li[t]; }
+        __syncthreads();
+    }
+    for (int k = 2 * C; k <= P && k > 0; k <<= 1) {
+        for (int j = k >> 1; j >= C; j >>= 1) {
+            for (int t = threadIdx.x; t < P; t += blockDim.x) {
+                const int u = t ^ j;
+                if (u > t) {
+                    const bool up = ((t & k) == 0);
+                    const uint64_t a = gk[t], b = gk[u];
+                    if ((a > b) == up) {
+                        gk[t] = b; gk[u] = a;
+                        const uint32_t ia = gi[t]; gi[t] = gi[u]; gi[u] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (C > 1) {
+            for (int base = 0; base < P; base += C) {
+                for (int t = threadIdx.x; t < C; t += blockDim.x) { lk[t] = gk[base + t]; li[t] = gi[base + t]; }
+                __syncthreads();
+                lds_bitonic_steps(lk, li, C, base, k, C >> 1);
+                for (int t = threadIdx.x; t < C; t += blockDim.x) { gk[base + t] = lk[t]; gi[base + t] = li[t]; }
+                __syncthreads();
+            }
+        }
+    }
+}
+// Greedy NMS of the first m entries of the sorted list (payload gi -> box through box_of).  kbox / karea / kid (global, m entries)
+// receive the kept boxes, their areas and payloads in pick order.  S: LDS carve with room for C entries.  Returns the kept count.
+template <bool MIN_MODE, class BoxOf>
+__device__ int big_greedy(const Smem& S, int C, const uint32_t* gi, int m, float thr, BoxOf box_of, float4* kbox, float* karea,
+                          uint32_t* kid) {
+    // kept boxes of earlier chunks are staged through LDS in tiles (the key area is idle during NMS: 8 C bytes = TK boxes + areas)
+    const int TK = (C * 8) / 20;
+    float4* tb = (float4*)S.key;
+    float* ta = (float*)(tb + TK);
+    constexpr int E = 2;                                  // entries of a chunk per thread: the spill tier runs with 1024 threads (C <= 2048)
+    int K = 0;
+    for (int base = 0; base < m; base += C) {
+        const int nc = m - base < C ? m - base : C;
+        float4 bt[E]; float at[E]; bool sp[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int t = threadIdx.x + e * blockDim.x;
+            sp[e] = true;                                 // (no entry)
+            if (t < nc) {
+                const uint32_t id = gi[base + t];
+                const float4 b = box_of(id);
+                bt[e] = b;
+                at[e] = MIN_MODE ? (b.z - b.x + 1.f) * (b.w - b.y + 1.f) : (b.z - b.x) * (b.w - b.y);
+                S.box[t] = b; S.area[t] = at[e]; S.id[t] = id;
+                sp[e] = false;
+            }
+        }
+        // boxes kept from earlier chunks: every thread tests its own entries of the chunk against a tile of them at a time
+        for (int k0 = 0; k0 < K; k0 += TK) {
+            const int nt = K - k0 < TK ? K - k0 : TK;
+            __syncthreads();
+            for (int i = threadIdx.x; i < nt; i += blockDim.x) { tb[i] = kbox[k0 + i]; ta[i] = karea[k0 + i]; }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (sp[e]) continue;
+                bool s = false;
+#pragma unroll 4
+                for (int k = 0; k < nt; k++) s |= nms_suppresses<MIN_MODE>(tb[k], ta[k], bt[e], at[e], thr);
+                sp[e] = s;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int t = threadIdx.x + e * blockDim.x;
+            if (t < nc) S.sup[t] = sp[e] ? 1 : 0;
+        }
+        __syncthreads();
+        const int nk = block_nms<MIN_MODE>(S.box, S.area, nc, thr, S.sup, S.keep, S.scal, true);
+        for (int r = threadIdx.x; r < nk; r += blockDim.x) {
+            const int t = S.keep[r];
+            kbox[K + r] = S.box[t]; karea[K + r] = S.area[t]; kid[K + r] = S.id[t];
+        }
+        K += nk;
+        __syncthreads();
+    }
+    return K;
+}
 
 // rerec() of one box
 __device__ __forceinline__ void rerec1(float& x1, float& y1, float& x2, float& y2) {
@@ -182,7 +362,7 @@ __global__ void k_area_level(const uint8_t* __restrict__ frames, int nf, int H, 
 
 // generateBoundingBox on the generic path: heads [nf][oh][ow][6] -> candidate records
 __global__ void k_pnet_collect(const float* __restrict__ heads, int nf, int f0, int oh, int ow, float scale, float thr,
-                               int L, int l, int cap, int32_t* __restrict__ lvl_cnt, Cand* __restrict__ lvl_rec,
+                               int L, int l, int cap, int rec0, int S, int32_t* __restrict__ lvl_cnt, Cand* __restrict__ lvl_rec,
                                int32_t* __restrict__ flags) {
     const size_t total = (size_t)nf * oh * ow;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -202,7 +382,7 @@ __global__ void k_pnet_collect(const float* __restrict__ heads, int nf, int f0, 
         c.score = p;
         c.r0 = hd[2]; c.r1 = hd[3]; c.r2 = hd[4]; c.r3 = hd[5];
         c.cell = cell;
-        lvl_rec[((size_t)f * L + l) * cap + slot] = c;
+        lvl_rec[(size_t)f * S + rec0 + slot] = c;
     }
 }
 
@@ -217,20 +397,44 @@ __global__ void k_heads_to_maps(const float* __restrict__ heads, int cells, floa
 // ---- stage 1a: per (frame, level) batched_nms(0.5) ------------------------------------------
 // Two launches share the segments: the SMALL tier (LDS sized for `lds_cap` = 512 candidates: ~24 KB, six workgroups per CU) takes
 // every segment with at most lds_cap candidates -- practically all of them: a level holds ~0.2 % of its cells -- and the FULL tier
-// (LDS for `cap` candidates: 94 KB, one workgroup per CU) only the crowded ones; a workgroup whose segment belongs to the other
-// tier exits at once.  One tier for everything ran the 2,816 segments of a 256-frame batch in eleven rounds of 256.
-__global__ __launch_bounds__(256) void k_nms_level(int L, int cap, int lds_cap, int min_cnt, const int32_t* __restrict__ lvl_cnt,
+// (LDS for 2048 candidates: 94 KB, one workgroup per CU) the crowded ones, through LDS up to its capacity and through the spill
+// tier (global memory) beyond; a workgroup whose segment belongs to the other tier exits at once.  One tier for everything ran
+// the 2,816 segments of a 256-frame batch in eleven rounds of 256.
+__global__ __launch_bounds__(1024) void k_nms_level(LvLayout G, int lds_cap, int min_cnt, int spill_tier, const int32_t* __restrict__ lvl_cnt,
                                                    const Cand* __restrict__ lvl_rec,
                                                    int32_t* __restrict__ keep_cnt, int32_t* __restrict__ keep_idx,
-                                                   int32_t* __restrict__ flags) {
+                                                   int32_t* __restrict__ flags, Spill sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem S(smem_raw, lds_cap);
+    Smem S(smem_raw, lds_cap, blockDim.x);
     const int seg = blockIdx.x;
+    const int f = seg / G.L, l = seg - f * G.L;
+    const int cap = G.capl[l];
     int cnt = lvl_cnt[seg];
-    if (cnt > cap) { cnt = cap; if (threadIdx.x == 0) flags[0] = 1; }
-    if (cnt > lds_cap || cnt < min_cnt) return;                 // the other tier's segment
+    // the small tier visits every segment: it reports the level's largest count (what the lists must hold: trl_cascade_check)
+    if (min_cnt == 0 && threadIdx.x == 0 && cnt > 0) atomicMax(&flags[FLG_LEVEL_MAX + l], cnt);
+    if (cnt > cap) { cnt = cap; if (threadIdx.x == 0) flags[FLG_LEVEL] = 1; }   // the call is re-run with longer lists
+    if (cnt < min_cnt || (cnt > lds_cap && !spill_tier)) return;                  // the other tier's segment
     if (cnt == 0) { if (threadIdx.x == 0) keep_cnt[seg] = 0; return; }
-    const Cand* recs = lvl_rec + (size_t)seg * cap;
+    const Cand* recs = lvl_rec + (size_t)f * G.S + G.rec0[l];
+    int32_t* kout = keep_idx + (size_t)f * G.S + G.rec0[l];
+    if (cnt > lds_cap) {                                                          // ---- spill tier
+        const int P = next_pow2(cnt);
+        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)cnt * 20);
+        if (!w) { if (threadIdx.x == 0) keep_cnt[seg] = 0; return; }
+        uint64_t* gk = (uint64_t*)w; uint32_t* gi = (uint32_t*)(gk + P);
+        float4* kbox = (float4*)(gi + P); float* karea = (float*)(kbox + cnt);
+        for (int t = threadIdx.x; t < P; t += blockDim.x) {
+            gk[t] = t < cnt ? (((uint64_t)(~f2ord(recs[t].score))) << 32) | (uint32_t)recs[t].cell : ~0ull;
+            gi[t] = t;
+        }
+        __syncthreads();
+        big_bitonic(gk, gi, P, S.key, S.id, pow2_floor(lds_cap));
+        const int nk = big_greedy<false>(S, pow2_floor(lds_cap), gi, cnt, 0.5f,
+                                         [&](uint32_t id) { const Cand& c = recs[id]; return make_float4(c.x1, c.y1, c.x2, c.y2); },
+                                         kbox, karea, (uint32_t*)kout);
+        if (threadIdx.x == 0) keep_cnt[seg] = nk;
+        return;
+    }
     const int P = next_pow2(cnt);
     for (int t = threadIdx.x; t < P; t += blockDim.x) {
         S.key[t] = t < cnt ? (((uint64_t)(~f2ord(recs[t].score))) << 32) | (uint32_t)recs[t].cell : ~0ull;
@@ -245,40 +449,90 @@ __global__ __launch_bounds__(256) void k_nms_level(int L, int cap, int lds_cap, 
     }
     __syncthreads();
     const int nk = block_nms<false>(S.box, S.area, cnt, 0.5f, S.sup, S.keep, S.scal);
-    for (int r = threadIdx.x; r < nk; r += blockDim.x) keep_idx[(size_t)seg * cap + r] = (int)S.id[S.keep[r]];
+    for (int r = threadIdx.x; r < nk; r += blockDim.x) kout[r] = (int)S.id[S.keep[r]];
     if (threadIdx.x == 0) keep_cnt[seg] = nk;
 }
 
 // ---- stage 1b: per frame batched_nms(0.7) over all levels, regress, rerec ----------------------
-__global__ __launch_bounds__(256) void k_nms_frame(int L, int cap, int capF, int W, int H, const Cand* __restrict__ lvl_rec,
+// regress with the PNet offsets (w, h WITHOUT +1), rerec; ok = the clipped box is not empty
+__device__ __forceinline__ bool stage1_row(const Cand& c, int W, int H, float4& box) {
+    const float regw = c.x2 - c.x1, regh = c.y2 - c.y1;
+    float x1 = c.x1 + c.r0 * regw, y1 = c.y1 + c.r1 * regh, x2 = c.x2 + c.r2 * regw, y2 = c.y2 + c.r3 * regh;
+    rerec1(x1, y1, x2, y2);
+    int y, ey, x, ex;
+    box = make_float4(x1, y1, x2, y2);
+    return pad1(x1, y1, x2, y2, W, H, y, ey, x, ex);
+}
+__global__ __launch_bounds__(1024) void k_nms_frame(LvLayout G, int lds_cap, int capF, int W, int H, const Cand* __restrict__ lvl_rec,
                                                    const int32_t* __restrict__ keep_cnt, const int32_t* __restrict__ keep_idx,
-                                                   int32_t* __restrict__ n1, float* __restrict__ s1_box, int32_t* __restrict__ flags) {
+                                                   int32_t* __restrict__ n1, float* __restrict__ s1_box, int32_t* __restrict__ flags, Spill sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem S(smem_raw, capF);
+    Smem S(smem_raw, lds_cap, blockDim.x);
     __shared__ int offs[33];
-    const int f = blockIdx.x;
+    const int f = blockIdx.x, L = G.L;
     if (threadIdx.x == 0) {
         int run = 0;
         for (int l = 0; l < L; l++) { offs[l] = run; run += keep_cnt[f * L + l]; }
         offs[L] = run;
+        if (run > 0) atomicMax(&flags[FLG_FRAME_MAX], run);
+        if (run > capF) flags[FLG_FRAME] = 1;                                    // the call is re-run with longer per-frame lists
     }
     __syncthreads();
-    int total = offs[L];
-    if (total > capF) { total = capF; if (threadIdx.x == 0) flags[1] = 1; }
-    if (total == 0) { if (threadIdx.x == 0) n1[f] = 0; return; }
-    const Cand* frec = lvl_rec + (size_t)f * L * cap;
+    const int total = offs[L];
+    if (total == 0 || total > capF) { if (threadIdx.x == 0) n1[f] = 0; return; }
+    const Cand* frec = lvl_rec + (size_t)f * G.S;
+    const int32_t* fkeep = keep_idx + (size_t)f * G.S;
+    auto fill = [&](int e, uint64_t& key, uint32_t& gid) {   // entry e of the concatenated per-level pick lists
+        int l = 0;
+        while (e >= offs[l + 1]) l++;
+        gid = (uint32_t)(G.rec0[l] + fkeep[G.rec0[l] + (e - offs[l])]);
+        key = (((uint64_t)(~f2ord(frec[gid].score))) << 32) | (uint32_t)e;   // e = position in the concatenated list
+    };
+    float* fout = s1_box + (size_t)f * capF * 5;
+    if (total > lds_cap) {                                                        // ---- spill tier
+        const int P = next_pow2(total), C = pow2_floor(lds_cap);
+        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)total * 24);
+        if (!w) { if (threadIdx.x == 0) n1[f] = 0; return; }
+        uint64_t* gk = (uint64_t*)w; uint32_t* gi = (uint32_t*)(gk + P);
+        float4* kbox = (float4*)(gi + P); float* karea = (float*)(kbox + total); uint32_t* kid = (uint32_t*)(karea + total);
+        for (int e = threadIdx.x; e < P; e += blockDim.x) {
+            uint64_t k = ~0ull; uint32_t g = 0;
+            if (e < total) fill(e, k, g);
+            gk[e] = k; gi[e] = g;
+        }
+        __syncthreads();
+        big_bitonic(gk, gi, P, S.key, S.id, C);
+        const int nk = big_greedy<false>(S, C, gi, total, 0.7f,
+                                         [&](uint32_t id) { const Cand& c = frec[id]; return make_float4(c.x1, c.y1, c.x2, c.y2); },
+                                         kbox, karea, kid);
+        int out = 0;                                                              // rows written so far (ordered compaction, chunk by chunk)
+        for (int base = 0; base < nk; base += C) {
+            const int nc = nk - base < C ? nk - base : C;
+            for (int r = threadIdx.x; r < nc; r += blockDim.x) {
+                const Cand& c = frec[kid[base + r]];
+                float4 b;
+                S.flg[r] = stage1_row(c, W, H, b) ? 1 : 0;
+                S.box[r] = b; S.aux[r] = c.score;
+            }
+            __syncthreads();
+            const int m = block_compact_positions(S.flg, nc, S.pos, S.part);
+            for (int r = threadIdx.x; r < nc; r += blockDim.x) {
+                if (!S.flg[r]) continue;
+                float* o = fout + (size_t)(out + S.pos[r]) * 5;
+                const float4 b = S.box[r];
+                o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = S.aux[r];
+            }
+            out += m;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) n1[f] = out;
+        return;
+    }
     const int P = next_pow2(total);
     for (int e = threadIdx.x; e < P; e += blockDim.x) {
-        if (e < total) {
-            int l = 0;
-            while (e >= offs[l + 1]) l++;
-            const int slot = keep_idx[((size_t)f * L + l) * cap + (e - offs[l])];
-            const uint32_t gid = (uint32_t)(l * cap + slot);
-            S.key[e] = (((uint64_t)(~f2ord(frec[gid].score))) << 32) | (uint32_t)e;   // e = position in the concatenated list
-            S.id[e] = gid;
-        } else {
-            S.key[e] = ~0ull; S.id[e] = 0;
-        }
+        uint64_t k = ~0ull; uint32_t g = 0;
+        if (e < total) fill(e, k, g);
+        S.key[e] = k; S.id[e] = g;
     }
     __syncthreads();
     block_bitonic(S.key, S.id, P);
@@ -292,19 +546,16 @@ __global__ __launch_bounds__(256) void k_nms_frame(int L, int cap, int capF, int
     // regress with the PNet offsets (w,h WITHOUT +1), rerec, drop empty clipped boxes
     for (int r = threadIdx.x; r < nk; r += blockDim.x) {
         const Cand& c = frec[S.id[S.keep[r]]];
-        const float regw = c.x2 - c.x1, regh = c.y2 - c.y1;
-        float x1 = c.x1 + c.r0 * regw, y1 = c.y1 + c.r1 * regh, x2 = c.x2 + c.r2 * regw, y2 = c.y2 + c.r3 * regh;
-        rerec1(x1, y1, x2, y2);
-        int y, ey, x, ex;
-        S.flg[r] = pad1(x1, y1, x2, y2, W, H, y, ey, x, ex) ? 1 : 0;
-        S.box[r] = make_float4(x1, y1, x2, y2);   // box[] no longer needed by NMS
+        float4 b;
+        S.flg[r] = stage1_row(c, W, H, b) ? 1 : 0;
+        S.box[r] = b;   // box[] no longer needed by NMS
         S.aux[r] = c.score;
     }
     __syncthreads();
     const int m = block_compact_positions(S.flg, nk, S.pos, S.part);
     for (int r = threadIdx.x; r < nk; r += blockDim.x) {
         if (!S.flg[r]) continue;
-        float* o = s1_box + ((size_t)f * capF + S.pos[r]) * 5;
+        float* o = fout + (size_t)S.pos[r] * 5;
         const float4 b = S.box[r];
         o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = S.aux[r];
     }
@@ -351,21 +602,78 @@ __global__ void k_build_map(const int32_t* __restrict__ cnt, const int32_t* __re
 }
 
 // ---- stage 2 tail: thr1, batched_nms(0.7), bbreg, rerec ------------------------------------------
-__global__ __launch_bounds__(256) void k_stage2_post(int capF, int cap_total, int W, int H, float thr, const int32_t* __restrict__ n1,
+// bbreg (+1 widths) with the R-Net offsets g, rerec; ok = the clipped box is not empty
+__device__ __forceinline__ bool stage2_row(const float4 b, const float* g, int W, int H, float4& out) {
+    const float w = b.z - b.x + 1.f, h = b.w - b.y + 1.f;
+    float x1 = b.x + g[0] * w, y1 = b.y + g[1] * h, x2 = b.z + g[2] * w, y2 = b.w + g[3] * h;
+    rerec1(x1, y1, x2, y2);
+    int y, ey, x, ex;
+    out = make_float4(x1, y1, x2, y2);
+    return pad1(x1, y1, x2, y2, W, H, y, ey, x, ex);
+}
+__global__ __launch_bounds__(1024) void k_stage2_post(int lds_cap, int capF, int cap_total, int W, int H, float thr, const int32_t* __restrict__ n1,
                                                      const float* __restrict__ s1_box, const int32_t* __restrict__ off2,
                                                      const float* __restrict__ out6, int32_t* __restrict__ n2,
-                                                     float* __restrict__ s2_box) {
+                                                     float* __restrict__ s2_box, Spill sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem S(smem_raw, capF);
+    Smem S(smem_raw, lds_cap, blockDim.x);
     const int f = blockIdx.x;
     const int cnt = n1[f];
     // total past the launch capacity: out6 is incomplete, the call is re-run with a larger capacity (flag set by k_scan_counts)
     if (cnt == 0 || off2[gridDim.x] > cap_total) { if (threadIdx.x == 0) n2[f] = 0; return; }
     const float* logits = out6 + (size_t)off2[f] * 6;
     const float* fb = s1_box + (size_t)f * capF * 5;
+    float* fout = s2_box + (size_t)f * capF * 5;
     const int P = next_pow2(cnt);
     if (threadIdx.x == 0) S.scal[4] = 0;
     __syncthreads();
+    if (cnt > lds_cap) {                                                          // ---- spill tier
+        const int C = pow2_floor(lds_cap);
+        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)cnt * 24);
+        if (!w) { if (threadIdx.x == 0) n2[f] = 0; return; }
+        uint64_t* gk = (uint64_t*)w; uint32_t* gi = (uint32_t*)(gk + P);
+        float4* kbox = (float4*)(gi + P); float* karea = (float*)(kbox + cnt); uint32_t* kid = (uint32_t*)(karea + cnt);
+        int mine = 0;
+        for (int i = threadIdx.x; i < P; i += blockDim.x) {
+            uint64_t k = ~0ull;
+            if (i < cnt) {
+                const float p = trl_softmax2_p1(logits[6 * i], logits[6 * i + 1]);
+                if (p > thr) { k = (((uint64_t)(~f2ord(p))) << 32) | (uint32_t)i; mine++; }
+            }
+            gk[i] = k; gi[i] = i;
+        }
+        if (mine) atomicAdd(&S.scal[4], mine);
+        __syncthreads();
+        const int m = S.scal[4];
+        __syncthreads();                                                          // (scal is reused by the NMS below)
+        if (m == 0) { if (threadIdx.x == 0) n2[f] = 0; return; }
+        big_bitonic(gk, gi, P, S.key, S.id, C);
+        const int nk = big_greedy<false>(S, C, gi, m, 0.7f,
+                                         [&](uint32_t i) { const float* b = fb + 5 * i; return make_float4(b[0], b[1], b[2], b[3]); },
+                                         kbox, karea, kid);
+        int out = 0;
+        for (int base = 0; base < nk; base += C) {
+            const int nc = nk - base < C ? nk - base : C;
+            for (int r = threadIdx.x; r < nc; r += blockDim.x) {
+                const int i = (int)kid[base + r];
+                float4 b;
+                S.flg[r] = stage2_row(kbox[base + r], logits + 6 * i + 2, W, H, b) ? 1 : 0;
+                S.box[r] = b; S.aux[r] = trl_softmax2_p1(logits[6 * i], logits[6 * i + 1]);
+            }
+            __syncthreads();
+            const int mm = block_compact_positions(S.flg, nc, S.pos, S.part);
+            for (int r = threadIdx.x; r < nc; r += blockDim.x) {
+                if (!S.flg[r]) continue;
+                float* o = fout + (size_t)(out + S.pos[r]) * 5;
+                const float4 b = S.box[r];
+                o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = S.aux[r];
+            }
+            out += mm;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) n2[f] = out;
+        return;
+    }
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         uint64_t k = ~0ull;
         if (i < cnt) {
@@ -389,15 +697,10 @@ __global__ __launch_bounds__(256) void k_stage2_post(int capF, int cap_total, in
     // bbreg (+1 widths), rerec; rows go to s2_box provisionally at r, then are compacted in place
     for (int r = threadIdx.x; r < nk; r += blockDim.x) {
         const int i = (int)S.id[S.keep[r]];
-        const float4 b = S.box[S.keep[r]];
-        const float* g = logits + 6 * i + 2;
-        const float w = b.z - b.x + 1.f, h = b.w - b.y + 1.f;
-        float x1 = b.x + g[0] * w, y1 = b.y + g[1] * h, x2 = b.z + g[2] * w, y2 = b.w + g[3] * h;
-        rerec1(x1, y1, x2, y2);
-        int y, ey, x, ex;
-        S.flg[r] = pad1(x1, y1, x2, y2, W, H, y, ey, x, ex) ? 1 : 0;
-        float* o = s2_box + ((size_t)f * capF + r) * 5;
-        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = S.aux[i];
+        float4 b;
+        S.flg[r] = stage2_row(S.box[S.keep[r]], logits + 6 * i + 2, W, H, b) ? 1 : 0;
+        float* o = fout + (size_t)r * 5;
+        o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = S.aux[i];
     }
     __syncthreads();
     const int mm = block_compact_positions(S.flg, nk, S.pos, S.part);
@@ -406,20 +709,31 @@ __global__ __launch_bounds__(256) void k_stage2_post(int capF, int cap_total, in
     for (int base = 0; base < nk; base += blockDim.x) {
         const int r = base + threadIdx.x;
         bool live = r < nk && S.flg[r];
-        if (live) { const float* o = s2_box + ((size_t)f * capF + r) * 5; for (int q = 0; q < 5; q++) row[q] = o[q]; }
+        if (live) { const float* o = fout + (size_t)r * 5; for (int q = 0; q < 5; q++) row[q] = o[q]; }
         __syncthreads();
-        if (live) { float* o = s2_box + ((size_t)f * capF + S.pos[r]) * 5; for (int q = 0; q < 5; q++) o[q] = row[q]; }
+        if (live) { float* o = fout + (size_t)S.pos[r] * 5; for (int q = 0; q < 5; q++) o[q] = row[q]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) n2[f] = mm;
 }
 
 // ---- stage 3 tail: thr2, landmarks, bbreg, nms 'Min' 0.7 --------------------------------------
-__global__ __launch_bounds__(256) void k_stage3_post(int capF, int cap_total, float thr, const int32_t* __restrict__ n2, const float* __restrict__ s2_box,
+__device__ __forceinline__ float4 stage3_box(const float* b, const float* g) {   // bbreg (+1 widths) with the O-Net offsets
+    const float w = b[2] - b[0] + 1.f, h = b[3] - b[1] + 1.f;
+    return make_float4(b[0] + g[0] * w, b[1] + g[1] * h, b[2] + g[2] * w, b[3] + g[3] * h);
+}
+__device__ __forceinline__ void stage3_points(const float* b, const float* pt, float* po) {
+    const float w_i = b[2] - b[0] + 1.f, h_i = b[3] - b[1] + 1.f;
+    for (int j = 0; j < 5; j++) {
+        po[j] = w_i * pt[j] + b[0] - 1.f;
+        po[5 + j] = h_i * pt[5 + j] + b[1] - 1.f;
+    }
+}
+__global__ __launch_bounds__(1024) void k_stage3_post(int lds_cap, int capF, int cap_total, float thr, const int32_t* __restrict__ n2, const float* __restrict__ s2_box,
                                                      const int32_t* __restrict__ off3, const float* __restrict__ out16,
-                                                     int32_t* __restrict__ n3, float* __restrict__ s3_box, float* __restrict__ s3_pts) {
+                                                     int32_t* __restrict__ n3, float* __restrict__ s3_box, float* __restrict__ s3_pts, Spill sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem S(smem_raw, capF);
+    Smem S(smem_raw, lds_cap, blockDim.x);
     const int f = blockIdx.x;
     const int cnt = n2[f];
     if (cnt == 0 || off3[gridDim.x] > cap_total) { if (threadIdx.x == 0) n3[f] = 0; return; }   // see k_stage2_post
@@ -428,6 +742,39 @@ __global__ __launch_bounds__(256) void k_stage3_post(int capF, int cap_total, fl
     const int P = next_pow2(cnt);
     if (threadIdx.x == 0) S.scal[4] = 0;
     __syncthreads();
+    if (cnt > lds_cap) {                                                          // ---- spill tier
+        const int C = pow2_floor(lds_cap);
+        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)cnt * 24);
+        if (!w) { if (threadIdx.x == 0) n3[f] = 0; return; }
+        uint64_t* gk = (uint64_t*)w; uint32_t* gi = (uint32_t*)(gk + P);
+        float4* kbox = (float4*)(gi + P); float* karea = (float*)(kbox + cnt); uint32_t* kid = (uint32_t*)(karea + cnt);
+        int mine = 0;
+        for (int i = threadIdx.x; i < P; i += blockDim.x) {
+            uint64_t k = ~0ull;
+            if (i < cnt) {
+                const float p = trl_softmax2_p1(logits[16 * i], logits[16 * i + 1]);
+                if (p > thr) { k = (((uint64_t)(~f2ord(p))) << 32) | (uint32_t)(~(uint32_t)i); mine++; }
+            }
+            gk[i] = k; gi[i] = i;
+        }
+        if (mine) atomicAdd(&S.scal[4], mine);
+        __syncthreads();
+        const int m = S.scal[4];
+        __syncthreads();
+        if (m == 0) { if (threadIdx.x == 0) n3[f] = 0; return; }
+        big_bitonic(gk, gi, P, S.key, S.id, C);
+        const int nk = big_greedy<true>(S, C, gi, m, 0.7f,
+                                        [&](uint32_t i) { return stage3_box(fb + 5 * i, logits + 16 * i + 2); }, kbox, karea, kid);
+        for (int r = threadIdx.x; r < nk; r += blockDim.x) {
+            const int i = (int)kid[r];
+            const float4 bb = kbox[r];
+            float* o = s3_box + ((size_t)f * capF + r) * 5;
+            o[0] = bb.x; o[1] = bb.y; o[2] = bb.z; o[3] = bb.w; o[4] = trl_softmax2_p1(logits[16 * i], logits[16 * i + 1]);
+            stage3_points(fb + 5 * i, logits + 16 * i + 6, s3_pts + ((size_t)f * capF + r) * 10);
+        }
+        if (threadIdx.x == 0) n3[f] = nk;
+        return;
+    }
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         uint64_t k = ~0ull;
         if (i < cnt) {
@@ -444,12 +791,9 @@ __global__ __launch_bounds__(256) void k_stage3_post(int capF, int cap_total, fl
     block_bitonic(S.key, S.id, P);
     for (int t = threadIdx.x; t < m; t += blockDim.x) {
         const int i = (int)S.id[t];
-        const float* b = fb + 5 * i;
-        const float* g = logits + 16 * i + 2;
-        const float w = b[2] - b[0] + 1.f, h = b[3] - b[1] + 1.f;
-        const float x1 = b[0] + g[0] * w, y1 = b[1] + g[1] * h, x2 = b[2] + g[2] * w, y2 = b[3] + g[3] * h;   // bbreg
-        S.box[t] = make_float4(x1, y1, x2, y2);
-        S.area[t] = (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
+        const float4 bb = stage3_box(fb + 5 * i, logits + 16 * i + 2);
+        S.box[t] = bb;
+        S.area[t] = (bb.z - bb.x + 1.f) * (bb.w - bb.y + 1.f);
     }
     __syncthreads();
     const int nk = block_nms<true>(S.box, S.area, m, 0.7f, S.sup, S.keep, S.scal);
@@ -458,14 +802,7 @@ __global__ __launch_bounds__(256) void k_stage3_post(int capF, int cap_total, fl
         const float4 bb = S.box[t];
         float* o = s3_box + ((size_t)f * capF + r) * 5;
         o[0] = bb.x; o[1] = bb.y; o[2] = bb.z; o[3] = bb.w; o[4] = S.aux[i];
-        const float* b = fb + 5 * i;
-        const float* pt = logits + 16 * i + 6;
-        const float w_i = b[2] - b[0] + 1.f, h_i = b[3] - b[1] + 1.f;
-        float* po = s3_pts + ((size_t)f * capF + r) * 10;
-        for (int j = 0; j < 5; j++) {
-            po[j] = w_i * pt[j] + b[0] - 1.f;
-            po[5 + j] = h_i * pt[5 + j] + b[1] - 1.f;
-        }
+        stage3_points(fb + 5 * i, logits + 16 * i + 6, s3_pts + ((size_t)f * capF + r) * 10);
     }
     if (threadIdx.x == 0) n3[f] = nk;
 }
@@ -714,30 +1051,80 @@ int trl_launch_crop_resize80(const uint8_t* d_frames, int n, int H, int W, const
 
 
 
+// Record slots per level and rows per frame of this call: the configured start values, raised to what recent calls needed
+// (trl_cascade_check), never beyond what the geometry can produce (a level has oh x ow cells; a frame's stage-1 list is a subset
+// of its cells) -- so a frame small enough cannot overflow at all.
+static void plan_lists(trl_ctx* c, int L) {
+    CascadeBufs& B = c->cb;
+    LvLayout& G = B.lay;
+    G = LvLayout();
+    G.L = L;
+    long long cells_total = 0;
+    int S = 0;
+    for (int l = 0; l < L; l++) {
+        const long long cells = (long long)c->lv[l].oh * c->lv[l].ow;
+        long long want = c->cfg.cap_level;
+        if ((long long)c->lvl_hint[l] > want) want = (long long)c->lvl_hint[l];
+        if (want > cells) want = cells;
+        if (want < 4) want = 4;
+        G.capl[l] = (int)((want + 3) & ~3ll);
+        G.rec0[l] = S;
+        S += G.capl[l];
+        cells_total += cells;
+    }
+    G.S = S;
+    long long wantF = c->cfg.cap_frame;
+    if ((long long)c->frame_hint > wantF) wantF = (long long)c->frame_hint;
+    if (wantF > cells_total) wantF = cells_total;
+    if (wantF < 4) wantF = 4;
+    B.capF = (int)((wantF + 3) & ~3ll);
+}
+static size_t spill_need(long long cnt) {   // workspace of one spilled list of cnt entries (k_nms_level .. k_stage3_post)
+    long long P = 2;
+    while (P < cnt) P <<= 1;
+    return (size_t)(P * 12 + cnt * 24 + 256);
+}
+
 // detect_face() stages 1-3 for n frames; results stay in c->cb
 int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipStream_t s) {
-    const int cap = c->cfg.cap_level, capF = c->cfg.cap_frame;
     const int L = trl_compute_levels(c, H, W);
     CascadeBufs& B = c->cb;
     B.n = n; B.L = L; B.H = H; B.W = W;
+    plan_lists(c, L);
+    const LvLayout& G = B.lay;
+    const int capF = B.capF;
+    const int lds_full = c->nms_full, lds_small = c->nms_small < c->nms_full ? c->nms_small : c->nms_full;
+    // spill workspace: lists that can outgrow the LDS tier get theirs up front (bounded; a pool that still runs out is grown by the re-run)
+    size_t spill = c->spill_hint;
+    {
+        size_t per_frame = 0;
+        for (int l = 0; l < L; l++) if (G.capl[l] > lds_full) per_frame += spill_need(G.capl[l]);
+        if (capF > lds_full) per_frame += 3 * spill_need(capF);
+        size_t up_front = per_frame * (size_t)n;
+        if (up_front > (8ull << 30)) up_front = 8ull << 30;
+        if (up_front > spill) spill = up_front;
+    }
     Arena& A = c->arena;      // cascade lists: live for the whole call (and for the debug hooks after it)
     Arena& X = c->scratch;    // activations: reset between stages
-    const size_t need = (size_t)n * L * ((size_t)cap * (sizeof(Cand) + 4) + 8) + (size_t)n * capF * (5 * 3 + 10 + 8) * 4 +
-                        (size_t)n * 1024 + (1u << 20);   // + the API layer's per-frame outputs (box0, prob0, rect, valid, pts0)
+    const size_t need = (size_t)n * ((size_t)G.S * (sizeof(Cand) + 4) + (size_t)L * 8) + (size_t)n * capF * (5 * 3 + 10 + 8) * 4 +
+                        (size_t)n * 1024 + spill + (1u << 20);   // + the API layer's per-frame outputs (box0, prob0, rect, valid, pts0)
     TRL_CHECK(trl_ensure(c, A, need));
     A.reset();
     B.lvl_cnt = (int32_t*)A.alloc((size_t)n * L * 4);
     B.lvl_keep_cnt = (int32_t*)A.alloc((size_t)n * L * 4);
-    B.lvl_rec = (Cand*)A.alloc((size_t)n * L * cap * sizeof(Cand));
-    B.lvl_keep_idx = (int32_t*)A.alloc((size_t)n * L * cap * 4);
+    B.lvl_rec = (Cand*)A.alloc((size_t)n * G.S * sizeof(Cand));
+    B.lvl_keep_idx = (int32_t*)A.alloc((size_t)n * G.S * 4);
     B.n1 = (int32_t*)A.alloc((size_t)n * 4); B.n2 = (int32_t*)A.alloc((size_t)n * 4); B.n3 = (int32_t*)A.alloc((size_t)n * 4);
     B.s1_box = (float*)A.alloc((size_t)n * capF * 20); B.s2_box = (float*)A.alloc((size_t)n * capF * 20);
     B.s3_box = (float*)A.alloc((size_t)n * capF * 20); B.s3_pts = (float*)A.alloc((size_t)n * capF * 40);
     B.off2 = (int32_t*)A.alloc((size_t)(n + 1) * 4); B.off3 = (int32_t*)A.alloc((size_t)(n + 1) * 4);
     B.cbox = (int32_t*)A.alloc((size_t)n * capF * 32);
-    B.flags = (int32_t*)A.alloc(64);
-    if (!B.flags) { trl_set_error("cascade workspace allocation failed"); return TRL_ERR_STATE; }
-    TRL_HIP(hipMemsetAsync(B.flags, 0, 64, s));
+    B.flags = (int32_t*)A.alloc(TRL_NFLAGS * 4);
+    B.spill = spill ? (char*)A.alloc(spill) : nullptr;
+    B.spill_cap = B.spill ? spill : 0;
+    if (!B.flags || (spill && !B.spill)) { trl_set_error("cascade workspace allocation failed"); return TRL_ERR_STATE; }
+    TRL_HIP(hipMemsetAsync(B.flags, 0, TRL_NFLAGS * 4, s));
+    const Spill sp{B.spill, (unsigned long long)B.spill_cap, B.flags};
     if (L == 0) {
         // min(H, W) * 12 / min_face_size < 12: detect_face() builds no scale at all and returns no boxes (the frame is smaller
         // than the smallest face looked for).  Every stage count is zero; k_select then reports "no face" for every frame.
@@ -755,7 +1142,9 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     c->pnet_ev_used = 0;
     X.reset();
     int chunk[32];
-    if (c->cfg.pnet_mode != 0) {
+    const bool fused = c->cfg.pnet_mode == 0 && L <= 16;   // the fused launch carries 16 level descriptors; taller pyramids (a
+                                                           // 16 K frame at min_face_size 12) take the per-level path
+    if (!fused) {
         size_t mx = 0;
         for (int l = 0; l < L; l++) {
             const LevelGeom& g = c->lv[l];
@@ -790,11 +1179,11 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         size_t need_x = (size_t)c->cap_t2 * 24 + (size_t)ch2 * (40 * 1024) + (1u << 20);
         const size_t need3 = (size_t)c->cap_t3 * 64 + (size_t)ch3 * (240 * 1024) + (1u << 20);
         if (need3 > need_x) need_x = need3;
-        if (c->cfg.pnet_mode == 0) { const size_t p = trl_pnet_fused_bytes(c, n, H, W) + (1u << 20); if (p > need_x) need_x = p; }
+        if (fused) { const size_t p = trl_pnet_fused_bytes(c, n, H, W) + (1u << 20); if (p > need_x) need_x = p; }
         if (c->scratch_after_cascade > need_x) need_x = c->scratch_after_cascade;   // the embedder that follows in the same call
         TRL_CHECK(trl_ensure(c, X, need_x));
     }
-    if (c->cfg.pnet_mode == 0) {
+    if (fused) {
         // fused path: pyramid kernel + ONE persistent PNet launch over every (frame, level, tile)
         std::pair<hipEvent_t, hipEvent_t>*pa, *pb;
         c->pnet_ev.reserve(64);   // next_ev hands out pointers into the vector: no reallocation below
@@ -820,29 +1209,35 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
                 const size_t total = (size_t)nf * g.oh * g.ow;
                 size_t blocks = (total + 255) / 256;
                 if (blocks > 16384) blocks = 16384;
-                k_pnet_collect<<<(unsigned)blocks, 256, 0, s>>>(heads, nf, f0, g.oh, g.ow, (float)g.scale, c->cfg.thr0, L, l, cap,
-                                                                 B.lvl_cnt, B.lvl_rec, B.flags);
+                k_pnet_collect<<<(unsigned)blocks, 256, 0, s>>>(heads, nf, f0, g.oh, g.ow, (float)g.scale, c->cfg.thr0, L, l, G.capl[l],
+                                                                 G.rec0[l], G.S, B.lvl_cnt, B.lvl_rec, B.flags);
                 TRL_LAUNCH_CHECK();
             }
             TRL_HIP(hipEventRecord(pe->second, s));
         }
     }
-    const size_t sm_l = Smem::bytes(cap), sm_f = Smem::bytes(capF);
+    // LDS tiers: no list is longer than its capacity, so the carve never exceeds what the call can produce
+    int max_capl = 4;
+    for (int l = 0; l < L; l++) if (G.capl[l] > max_capl) max_capl = G.capl[l];
+    const int full_l = max_capl < lds_full ? max_capl : lds_full, full_f = capF < lds_full ? capF : lds_full;
+    // lists that can take the spill tier run with 1024 threads per workgroup: its cost is pair tests (candidates x boxes kept so far)
+    const int th_l = max_capl > lds_full ? 1024 : 256, th_f = capF > lds_full ? 1024 : 256;
+    const size_t sm_l = Smem::bytes(full_l, th_l), sm_f = Smem::bytes(full_f, th_f);
     TRL_CHECK(set_dyn_smem(k_nms_level, sm_l));
     TRL_CHECK(set_dyn_smem(k_nms_frame, sm_f));
     TRL_CHECK(set_dyn_smem(k_stage2_post, sm_f));
     TRL_CHECK(set_dyn_smem(k_stage3_post, sm_f));
     {
-        const int small_cap = cap < 512 ? cap : 512;
+        const int small_cap = full_l < lds_small ? full_l : lds_small;
         const size_t sm_s = Smem::bytes(small_cap);
-        k_nms_level<<<n * L, 256, sm_s, s>>>(L, cap, small_cap, 0, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags);
+        k_nms_level<<<n * L, 256, sm_s, s>>>(G, small_cap, 0, small_cap == max_capl ? 1 : 0, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags, sp);
         TRL_LAUNCH_CHECK();
-        if (small_cap < cap) {
-            k_nms_level<<<n * L, 256, sm_l, s>>>(L, cap, cap, small_cap + 1, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags);
+        if (small_cap < max_capl) {
+            k_nms_level<<<n * L, th_l, sm_l, s>>>(G, full_l, small_cap + 1, 1, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags, sp);
             TRL_LAUNCH_CHECK();
         }
     }
-    k_nms_frame<<<n, 256, sm_f, s>>>(L, cap, capF, W, H, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.n1, B.s1_box, B.flags);
+    k_nms_frame<<<n, th_f, sm_f, s>>>(G, full_f, capF, W, H, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.n1, B.s1_box, B.flags, sp);
     TRL_LAUNCH_CHECK();
 
     // ---- stage 2: RNet ------------------------------------------------------------------------------
@@ -868,7 +1263,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
             TRL_CHECK(trl_run_rnet_tail(c, pool1, nc, out6 + (size_t)t0 * 6, s, B.off2 + n, t0));
         }
     }
-    k_stage2_post<<<n, 256, sm_f, s>>>(capF, cap2, W, H, c->cfg.thr1, B.n1, B.s1_box, B.off2, out6, B.n2, B.s2_box);
+    k_stage2_post<<<n, th_f, sm_f, s>>>(full_f, capF, cap2, W, H, c->cfg.thr1, B.n1, B.s1_box, B.off2, out6, B.n2, B.s2_box, sp);
     TRL_LAUNCH_CHECK();
 
     // ---- stage 3: ONet --------------------------------------------------------------------------------
@@ -890,7 +1285,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
             TRL_CHECK(trl_run_onet_tail(c, pool1, nc, out16 + (size_t)t0 * 16, s, B.off3 + n, t0));
         }
     }
-    k_stage3_post<<<n, 256, sm_f, s>>>(capF, cap3, c->cfg.thr2, B.n2, B.s2_box, B.off3, out16, B.n3, B.s3_box, B.s3_pts);
+    k_stage3_post<<<n, th_f, sm_f, s>>>(full_f, capF, cap3, c->cfg.thr2, B.n2, B.s2_box, B.off3, out16, B.n3, B.s3_box, B.s3_pts, sp);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }
@@ -899,36 +1294,62 @@ int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
                        int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, float* d_pts0, hipStream_t s) {
     (void)d_frames;
     CascadeBufs& B = c->cb;
-    k_select<<<n, 64, 0, s>>>(c->cfg.cap_frame, c->cfg.max_faces, W, H, B.n3, B.s3_box, B.s3_pts, d_boxes, d_probs, d_points, d_counts, d_box0, d_prob0,
+    k_select<<<n, 64, 0, s>>>(B.capF, c->cfg.max_faces, W, H, B.n3, B.s3_box, B.s3_pts, d_boxes, d_probs, d_points, d_counts, d_box0, d_prob0,
                               d_rect, d_valid, d_pts0);
     TRL_LAUNCH_CHECK();
     // overflow flags + stage totals travel to pinned host memory behind the kernels; trl_cascade_check reads them after the
     // call's ONE stream synchronisation (no host round trip inside the call)
-    TRL_HIP(hipMemcpyAsync(c->h_pinned + 4, B.flags, 32, hipMemcpyDeviceToHost, s));
+    TRL_HIP(hipMemcpyAsync(c->h_pinned + 4, B.flags, TRL_NFLAGS * 4, hipMemcpyDeviceToHost, s));
     return TRL_OK;
 }
 
-// After the stream has been synchronised.  TRL_OK; TRL_ERR_CAPACITY (a configured list capacity was exceeded: an error, never
-// a silent truncation); or *retry = 1 when the optimistic R-/O-Net batch capacity was too small -- the capacities have been
-// raised and the caller runs the call again (results of the first attempt are incomplete, not wrong-but-plausible).
+// After the stream has been synchronised.  *retry = 1 when a capacity of this attempt was too small -- a level's record list, a
+// frame's box list, the spill workspace, or the optimistic R-/O-Net batch -- : the capacities have been raised to what the
+// attempt measured and the caller runs the call again (results of the attempt are incomplete, not wrong-but-plausible, and are
+// never delivered).  No input can make this fail: detect_face() (server/model.py:47) has no candidate limit.
 int trl_cascade_check(trl_ctx* c, int n, int* retry) {
-    const int32_t* f = c->h_pinned + 4;   // [0] cap_level, [1] cap_frame, [2] T2 overflow, [3] T3 overflow, [4] T2, [5] T3
+    const int32_t* f = c->h_pinned + 4;
+    const int L = c->cb.L;
     *retry = 0;
-    if (f[0] || f[1]) {
-        trl_set_error("candidate list overflow (cap_level=%d%s, cap_frame=%d%s): raise the capacities in trl_config",
-                      c->cfg.cap_level, f[0] ? " EXCEEDED" : "", c->cfg.cap_frame, f[1] ? " EXCEEDED" : "");
-        return TRL_ERR_CAPACITY;
+    unsigned long long spill_used = 0;
+    memcpy(&spill_used, f + FLG_SPILL_CUR, 8);
+    if (f[FLG_LEVEL]) {                                  // every later stage ran on truncated lists: their totals mean nothing
+        for (int l = 0; l < L; l++) {
+            const float want = 1.25f * (float)f[FLG_LEVEL_MAX + l] + 4.f;
+            if (f[FLG_LEVEL_MAX + l] > c->cb.lay.capl[l] && want > c->lvl_hint[l]) c->lvl_hint[l] = want;
+        }
+        *retry = 1;
+        return TRL_OK;
     }
+    if (f[FLG_SPILL]) {                                  // lists that found no workspace were dropped: later totals are incomplete
+        c->spill_hint = (size_t)spill_used * 2 + (16u << 20);
+        *retry = 1;
+        if (f[FLG_FRAME]) c->frame_hint = 1.25f * (float)f[FLG_FRAME_MAX] + 4.f;
+        return TRL_OK;
+    }
+    if (f[FLG_FRAME]) { c->frame_hint = 1.25f * (float)f[FLG_FRAME_MAX] + 4.f; *retry = 1; return TRL_OK; }
     // keep ~25 % headroom over the largest batch seen, so a drifting clip rarely needs a second attempt
-    const float want2 = 1.25f * (float)f[4] / (float)n + 1.f, want3 = 1.25f * (float)f[5] / (float)n + 1.f;
-    if (f[2]) { c->t2_per_frame = want2; *retry = 1; }       // stage 3 ran on an incomplete stage 2: its total is meaningless
-    else if (f[3]) { c->t3_per_frame = want3; *retry = 1; }
+    const float want2 = 1.25f * (float)f[FLG_T2N] / (float)n + 1.f, want3 = 1.25f * (float)f[FLG_T3N] / (float)n + 1.f;
+    if (f[FLG_T2]) { c->t2_per_frame = want2; *retry = 1; }       // stage 3 ran on an incomplete stage 2: its total is meaningless
+    else if (f[FLG_T3]) { c->t3_per_frame = want3; *retry = 1; }
     if (!*retry) {
         // follow the content: grow at once, decay 3 % per call towards what recent batches needed (never below the start values),
         // so one crowded batch does not inflate every later call's launches and workspace for the life of the context
         const float d2 = 0.97f * c->t2_per_frame, d3 = 0.97f * c->t3_per_frame;
         c->t2_per_frame = want2 > d2 ? want2 : (d2 > 160.f ? d2 : (c->t2_per_frame < 160.f ? c->t2_per_frame : 160.f));
         c->t3_per_frame = want3 > d3 ? want3 : (d3 > 48.f ? d3 : (c->t3_per_frame < 48.f ? c->t3_per_frame : 48.f));
+        for (int l = 0; l < L; l++) {                    // list capacities decay the same way (values below the configured start are ignored)
+            const float want = 1.25f * (float)f[FLG_LEVEL_MAX + l] + 4.f, d = 0.97f * c->lvl_hint[l];
+            c->lvl_hint[l] = want > d ? want : d;
+        }
+        {
+            const float want = 1.25f * (float)f[FLG_FRAME_MAX] + 4.f, d = 0.97f * c->frame_hint;
+            c->frame_hint = want > d ? want : d;
+        }
+        {
+            const size_t want = (size_t)spill_used + (spill_used >> 2), d = c->spill_hint - (c->spill_hint >> 5);
+            c->spill_hint = spill_used ? (want > d ? want : d) : (d > (1u << 20) ? d : 0);
+        }
     }
     return TRL_OK;
 }

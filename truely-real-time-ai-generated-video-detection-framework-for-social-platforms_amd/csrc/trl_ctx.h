@@ -15,20 +15,33 @@ struct LevelGeom {
     int oh, ow;      // PNet output map size
 };
 
+// Candidate lists of one call.  Level l of every frame owns capl[l] record slots (never more than the level has cells); a frame's
+// records are contiguous: record (f, l, slot) = lvl_rec[f * S + rec0[l] + slot], S = sum of capl.  The per-frame box lists of
+// stages 1-3 hold capF rows.  Both capacities follow the content: a call that overflows one is re-run with larger lists
+// (trl_cascade_check), so no input can make the detector fail -- detect_face() has no candidate limit either.
+struct LvLayout {
+    int L = 0, S = 0;
+    int capl[32] = {0}, rec0[32] = {0};
+};
 struct CascadeBufs {   // device pointers into the arena, valid until the next call
     int n = 0, L = 0, H = 0, W = 0;
+    LvLayout lay;                    // record slots per level
+    int capF = 0;                    // rows per frame of s1_box / s2_box / s3_box / s3_pts
     int32_t* lvl_cnt = nullptr;      // [n][L]
-    Cand* lvl_rec = nullptr;         // [n][L][cap_level]
+    Cand* lvl_rec = nullptr;         // [n][S]
     int32_t* lvl_keep_cnt = nullptr; // [n][L]
-    int32_t* lvl_keep_idx = nullptr; // [n][L][cap_level]
-    int32_t* n1 = nullptr; float* s1_box = nullptr;   // [n], [n][cap_frame][5]
-    int32_t* n2 = nullptr; float* s2_box = nullptr;   // [n], [n][cap_frame][5]
-    int32_t* n3 = nullptr; float* s3_box = nullptr;   // [n], [n][cap_frame][5]
-    float* s3_pts = nullptr;                           // [n][cap_frame][10]
+    int32_t* lvl_keep_idx = nullptr; // [n][S]
+    int32_t* n1 = nullptr; float* s1_box = nullptr;   // [n], [n][capF][5]
+    int32_t* n2 = nullptr; float* s2_box = nullptr;   // [n], [n][capF][5]
+    int32_t* n3 = nullptr; float* s3_box = nullptr;   // [n], [n][capF][5]
+    float* s3_pts = nullptr;                           // [n][capF][10]
     int32_t* off2 = nullptr; int32_t* off3 = nullptr; // [n+1] exclusive scans of n1 / n2
-    int32_t* cbox = nullptr;     // [n*cap_frame][8]: candidate t of the current stage = {frame, y0, x0, ih, iw, 0, 0, 0} (pad()'s crop window)
-    int32_t* flags = nullptr;        // [4]: overflow flags
+    int32_t* cbox = nullptr;     // [n*capF][8]: candidate t of the current stage = {frame, y0, x0, ih, iw, 0, 0, 0} (pad()'s crop window)
+    int32_t* flags = nullptr;        // [TRL_NFLAGS]: see trl_cascade.hip
+    char* spill = nullptr;           // global-memory workspace of the NMS spill tier (lists longer than the LDS tier)
+    size_t spill_cap = 0;
 };
+enum { TRL_NFLAGS = 64 };            // int32 words of CascadeBufs::flags (copied to pinned host memory behind every call)
 
 struct trl_ctx {
     trl_config cfg;
@@ -59,6 +72,12 @@ struct trl_ctx {
     // exit early on the device; a call that overflows one is re-run with a larger value (trl_cascade.hip)
     float t2_per_frame = 160.f, t3_per_frame = 48.f;
     int cap_t2 = 0, cap_t3 = 0;      // capacities of the call in progress
+    // Candidate-list capacities follow the content the same way: the largest per-level count / per-frame stage-1 total / spill
+    // workspace recent calls needed (with head-room, decaying towards the configured start values)
+    float lvl_hint[32] = {0}, frame_hint = 0.f;
+    size_t spill_hint = 0;
+    int nms_small = 512, nms_full = 2048;   // LDS tiers of the sort + NMS kernels (candidates); longer lists take the spill tier
+                                            // (trl_debug_nms_tiers lowers them so that small test inputs reach every tier)
     int last_attempts = 0;           // attempts the last call took (test hook)
     size_t scratch_after_cascade = 0;   // scratch bytes the rest of the call needs (crops + FaceNet): sized with the cascade's
     int rnet_front_mode = -1, onet_front_mode = -1;   // conv1 PReLU slope class (trl_front.hip), -1 = not yet classified

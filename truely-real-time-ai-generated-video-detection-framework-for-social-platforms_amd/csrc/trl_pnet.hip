@@ -87,6 +87,7 @@ struct PLevel {
     unsigned hmagic;         // ceil(2^32 / h); with wmagic: bin edges by multiply-high when 'arith' (no table load in the
     int arith;               // dependent-latency chain of a pixel): requires H*h*h < 2^32 and W*w*w < 2^32
     float scale;
+    int cap, rec0;           // candidate records of the level: slots per frame, first slot inside a frame's block (LvLayout)
 };
 struct PnetArgs {
     const PyrPx* pyr; long long pyr_stride;    // pixels per frame
@@ -96,7 +97,7 @@ struct PnetArgs {
     PLevel lv[16];
     const float *w1, *w2, *w3, *wh;            // [Kpad][32] zero padded
     const float *b1, *b2, *b3, *bh, *s1, *s2, *s3;
-    float thr; int cap;
+    float thr; int rec_stride;                 // record slots per frame (LvLayout::S)
     float dthr;                                // logit-difference prefilter: no cell with logit1 - logit0 < dthr can reach thr (-inf: off)
     int dbg_skip;                              // timing-only ablation mask (TRL_PNET_SKIP); read by the DBG instantiation only
     int32_t* lvl_cnt; Cand* lvl_rec; int32_t* flags;
@@ -1248,7 +1249,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                         if (p >= a.thr && !(dbg_skip & 32)) {      // (bit 32: timing-only ablations emit no candidates)
                             const int seg = f * a.L + l;
                             const int sl = atomicAdd(&a.lvl_cnt[seg], 1);
-                            if (sl < a.cap) {
+                            if (sl < a.lv[l].cap) {            // (scalar loads inside the rare branch: the tile descriptor stays as small as it was)
                                 Cand c;
                                 c.x1 = floorf((2.f * (float)ox + 1.f) / fscale);
                                 c.y1 = floorf((2.f * (float)oy + 1.f) / fscale);
@@ -1257,7 +1258,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
                                 c.score = p;
                                 c.r0 = hq[2]; c.r1 = hq[3]; c.r2 = __uint_as_float(u2[1]); c.r3 = __uint_as_float(u3[1]);
                                 c.cell = oy * g.ow + ox;
-                                a.lvl_rec[(size_t)seg * a.cap + sl] = c;
+                                a.lvl_rec[(size_t)f * a.rec_stride + a.lv[l].rec0 + sl] = c;
                             } else {
                                 a.flags[0] = 1;
                             }
@@ -1410,6 +1411,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
             for (int i = 0; i < g.w; i++) tab->push_back((uint32_t)(((long long)i * W) / g.w) | ((uint32_t)((((long long)i + 1) * W + g.w - 1) / g.w) << 16));
         }
         p.scale = (float)g.scale;
+        p.cap = c->cb.lay.capl[l]; p.rec0 = c->cb.lay.rec0[l];   // (set by trl_cascade_detect before the fused launch)
     }
     a.tiles_per_frame = tiles;
     a.tpf_magic = sdiv_magic(tiles);
@@ -1418,7 +1420,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
     a.w1 = trl_w(c, "pnet.conv1.w")->p; a.w2 = trl_w(c, "pnet.conv2.w")->p; a.w3 = trl_w(c, "pnet.conv3.w")->p; a.wh = trl_w(c, "pnet.heads.w")->p;
     a.b1 = trl_v(c, "pnet.conv1.b")->p; a.b2 = trl_v(c, "pnet.conv2.b")->p; a.b3 = trl_v(c, "pnet.conv3.b")->p; a.bh = trl_v(c, "pnet.heads.b")->p;
     a.s1 = trl_v(c, "pnet.prelu1")->p; a.s2 = trl_v(c, "pnet.prelu2")->p; a.s3 = trl_v(c, "pnet.prelu3")->p;
-    a.thr = c->cfg.thr0; a.cap = c->cfg.cap_level;
+    a.thr = c->cfg.thr0; a.rec_stride = c->cb.lay.S;
     // p = softmax(logit0, logit1)[1] >= thr needs logit1 - logit0 >= ln(thr / (1 - thr)) up to the rounding of the float softmax
     // (~1e-6 relative); 0.05 below that bound the probability is short of thr by 0.05 thr (1 - thr) >= 4.9e-4 for thr in [0.01, 0.99]
     a.dthr = (a.thr >= 0.01f && a.thr <= 0.99f) ? (float)(log((double)a.thr / (1.0 - (double)a.thr)) - 0.05) : -__builtin_inff();

@@ -217,9 +217,12 @@ class Engine:
         return {"score": r[0], "run": r[1], "hits": r[2], "total": r[3], "sims": sims, "flags": flags}
 
     # ---- inspection hooks (parity tests) ----
-    def stage_boxes(self, stage: int, frame: int, max_rows: int = 4096) -> np.ndarray:
-        buf = np.zeros((max_rows, 5), np.float32)
+    def stage_boxes(self, stage: int, frame: int, max_rows: int | None = None) -> np.ndarray:
         k = C.c_int()
+        if max_rows is None:                              # every row the stage produced
+            _lib.check(self.lib.trl_debug_stage_boxes(self._h, stage, frame, None, 0, C.byref(k)))
+            max_rows = max(1, k.value)
+        buf = np.zeros((max_rows, 5), np.float32)
         _lib.check(self.lib.trl_debug_stage_boxes(self._h, stage, frame, buf.ctypes.data_as(C.c_void_p), max_rows, C.byref(k)))
         return buf[:min(k.value, max_rows)].copy()
 
@@ -238,6 +241,18 @@ class Engine:
         k = C.c_int()
         _lib.check(self.lib.trl_debug_batch_capacity(self._h, float(t2_per_frame), float(t3_per_frame), C.byref(k)))
         return k.value
+
+    def nms_tiers(self, small: int = 0, full: int = 0):
+        """Test hook: LDS tiers (candidates per list) of the sort + NMS kernels; lists longer than ``full`` take the
+        global-memory spill tier.  Results never depend on the tiers."""
+        _lib.check(self.lib.trl_debug_nms_tiers(self._h, int(small), int(full)))
+
+    def list_stats(self) -> dict:
+        """Candidate-list statistics of the last call (attempts, lists in the spill tier, capacities, largest counts)."""
+        t = (C.c_longlong * 8)()
+        _lib.check(self.lib.trl_debug_list_stats(self._h, t))
+        keys = ("attempts", "spill_lists", "spill_used", "spill_cap", "cap_frame", "slots_per_frame", "max_level_count", "max_frame_total")
+        return dict(zip(keys, (int(v) for v in t)))
 
     def pnet_run(self, run: int = 0):
         """Test / tuning hook: tiles per cursor fetch of the fused PNet launch (0 = automatic); > 1 exercises the halo carry."""
@@ -263,8 +278,9 @@ class Engine:
 
     def level_cands(self, frame: int, level: int) -> np.ndarray:
         """Test hook: the candidate records the PNet kernel appended for (frame, level) in the last call, sorted by cell."""
-        buf = np.zeros((self.cfg.cap_level,), self.CAND_DTYPE)
         k = C.c_int()
+        _lib.check(self.lib.trl_debug_level_cands(self._h, int(frame), int(level), None, 0, C.byref(k)))
+        buf = np.zeros((max(1, k.value),), self.CAND_DTYPE)
         _lib.check(self.lib.trl_debug_level_cands(self._h, int(frame), int(level), buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(k)))
         rows = buf[:min(k.value, len(buf))]
         return rows[np.argsort(rows["cell"], kind="stable")].copy()
