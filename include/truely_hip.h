@@ -144,11 +144,24 @@ int  trl_drift_score(trl_ctx* ctx, const float* d_emb, const uint8_t* d_valid, i
                      long long frame_count, int fps, float* d_sims, uint8_t* d_flags,
                      int32_t* d_result, void* stream);
 
+/* The same state machine continued across the WINDOWS of one clip, for callers that stream (model.run): d_state
+ * (TRL_DRIFT_STATE_BYTES device bytes, zero-filled before the clip's first window) carries what model.py's loop variables
+ * `previous_embedding`, `consecutive_count`, `ai_detected_frames` hold between two sampled frames (model.py:60-75).  The n
+ * embeddings of the window are compared in order, the first one with the carried embedding; d_sims / d_flags (may be NULL)
+ * cover the window; d_result as above, computed for `frame_count` = frames decoded so far (n = 0 with the clip's final count
+ * gives the final score).  Windows of any sizes give the similarities, flags and score of one trl_drift_score over the clip. (ABI v7) */
+#define TRL_DRIFT_STATE_BYTES 2064
+int  trl_drift_update(trl_ctx* ctx, void* d_state, const float* d_emb, const uint8_t* d_valid, int n,
+                      long long frame_count, int fps, float* d_sims, uint8_t* d_flags, int32_t* d_result, void* stream);
+
 /* SURVEY 8(f)-1, device-side ingest in place of the CPU decode + sampling at server/model.py:43,46:
  * d_nv12 holds n_in decoder-output frames (NV12: H*W luma bytes, then H/2 rows of interleaved U,V);
  * frames 0, step, 2*step, ... are converted to u8 BGR [n_out][H][W][3] (OpenCV's integer BT.601
  * limited-range arithmetic) ready for trl_detect_embed.  step = max(1, int(fps / 7)) (model.py:40). */
 int  trl_ingest_nv12(trl_ctx* ctx, const uint8_t* d_nv12, int n_in, int H, int W, int step,
+                     uint8_t* d_bgr, int* n_out, void* stream);
+/* the same for PLANAR 4:2:0 (I420: Y plane, U plane, V plane -- YUV4MPEG2 files, software decoders): no host-side repacking (ABI v7) */
+int  trl_ingest_i420(trl_ctx* ctx, const uint8_t* d_i420, int n_in, int H, int W, int step,
                      uint8_t* d_bgr, int* n_out, void* stream);
 
 /* ---- inspection hooks used by the parity tests (stage-by-stage vs the oracle) ------------- */

@@ -157,6 +157,52 @@ def test_nv12_ingest_with_sampling(engine, oracle):
         engine.ingest_nv12(nv12[:, :-3], H, W, step)
 
 
+def test_i420_ingest_equals_nv12_ingest(engine, oracle):
+    """Planar 4:2:0 (YUV4MPEG2 files, software decoders) converts on the device without host-side repacking: same bytes as the
+    NV12 path on the interleaved copy of the same chroma, and as the oracle."""
+    rng = np.random.default_rng(13)
+    n, H, W, step = 7, 36, 52, 3
+    nv12 = rng.integers(0, 256, (n, H * W * 3 // 2), dtype=np.uint8)
+    i420 = nv12.copy()
+    i420[:, H * W:H * W + H * W // 4] = nv12[:, H * W::2]
+    i420[:, H * W + H * W // 4:] = nv12[:, H * W + 1::2]
+    a = engine.ingest_nv12(nv12, H, W, step).cpu().numpy()
+    b = engine.ingest_nv12(i420, H, W, step, planar=True).cpu().numpy()
+    assert a.shape == (3, H, W, 3) and np.array_equal(a, b)
+    assert np.array_equal(b[1], oracle.nv12_to_bgr(nv12[3], H, W))
+
+
+def test_run_with_the_output_stage_skipped(engine, oracle, tmp_path, monkeypatch):
+    """TRUELY_WRITE_OUTPUT=0 (the analysis alone): only the sampled frames are read from containers with fixed-size frames, in
+    windows over two contexts with the embedder grouped over four windows -- several groups, a ragged last window, and a clip
+    shorter than one window.  BGR, NV12 and YUV4MPEG2 clips: the score is the oracle's on the sampled frames."""
+    from truely_amd import engine as eng_mod, model, video_io
+    from truely_amd.ingest import bgr_to_nv12
+    monkeypatch.setattr(eng_mod, "_default", engine)
+    monkeypatch.setenv("TRUELY_WRITE_OUTPUT", "0")
+    H, W, fps = 96, 128, 30
+    fr = truely_amd.synthetic.synthetic_frames(30, H, W, seed=3)
+    fr = np.concatenate([fr, fr[::-1], fr])[:87 * 4 - 2]                 # 346 frames -> 87 sampled
+    garbage = np.random.default_rng(0).integers(0, 256, fr.shape, dtype=np.uint8)
+    clip = np.where((np.arange(len(fr)) % 4 == 0)[:, None, None, None], fr, garbage)    # the frames in between are never analysed
+    nv = bgr_to_nv12(clip)
+    a, b, c = str(tmp_path / "in.trlv"), str(tmp_path / "in_nv12.trlv"), str(tmp_path / "in.y4m")
+    video_io.write_raw(a, clip, fps)
+    video_io.write_raw(b, nv, fps, pixfmt="nv12", size=(W, H))
+    video_io.write_y4m(c, nv, fps, (W, H))
+    r = oracle.detect_embed(clip[::4])
+    exp = oracle.drift_score(r["emb"], r["valid"], len(clip), fps)["score"]
+    bgr = np.stack([oracle.nv12_to_bgr(f, H, W) for f in nv[::4]])
+    r2 = oracle.detect_embed(bgr)
+    exp_yuv = oracle.drift_score(r2["emb"], r2["valid"], len(clip), fps)["score"]
+    for win_bytes in (16 * H * W * 3, 10 ** 9):                          # 16-frame windows (6 windows: 4 + 2 in two embedder groups), one window
+        monkeypatch.setattr(model, "WINDOW_BYTES", win_bytes)
+        assert model.run(a, str(tmp_path / "none.avi")) == exp
+        assert model.run(b, str(tmp_path / "none.avi")) == exp_yuv
+        assert model.run(c, str(tmp_path / "none.avi")) == exp_yuv
+    assert not os.path.exists(str(tmp_path / "none.avi"))
+
+
 def test_aligned_crop_kernel_bit_exact(engine, oracle):
     """Embedding mode 3's crop on chosen landmark sets: upright, rotated, scaled, partly outside the frame (replicated borders),
     degenerate (all five points equal: scale 0, every sample is one pixel) -- device = oracle bit for bit, and an exact

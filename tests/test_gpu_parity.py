@@ -459,6 +459,35 @@ def test_drift_score_matches_oracle(engine, oracle):
     assert np.array_equal(got["flags"].cpu().numpy(), ref["flags"])
 
 
+def test_drift_update_carries_the_state_machine_across_windows(engine, oracle):
+    """trl_drift_update: model.py's `previous_embedding` / `consecutive_count` / `ai_detected_frames` carried on the device from
+    window to window.  Windows of any sizes -- empty ones, single frames, windows that start or end inside a faceless gap, a
+    window longer than the scan's LDS chunk -- give the similarities, flags, counters and score of ONE pass over the clip."""
+    rng = np.random.default_rng(19)
+    n = 6000
+    base = rng.standard_normal(512).astype(np.float32)
+    noise = np.where((np.arange(n) // 130) % 2 == 0, 0.6, 0.01).astype(np.float32)
+    emb = base[None, :] + rng.standard_normal((n, 512)).astype(np.float32) * noise[:, None]
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    valid = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+    valid[:3] = 0                                        # the clip starts without a face
+    valid[40:75] = 0                                     # a gap that swallows whole windows
+    ref = oracle.drift_score(emb, valid, n * 4, 30)
+    cuts = [0, 1, 2, 2, 9, 41, 60, 61, 77, 128, 640, 640 + 4500, n]
+    state = engine.drift_state()
+    sims, flags = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        d = engine.drift_update(state, _t(emb[a:b]), _t(valid[a:b]), b * 4, 30)
+        part = oracle.drift_score(emb[:b], valid[:b], b * 4, 30)
+        assert (d["score"], d["run"], d["hits"]) == (part["score"], part["run"], part["hits"]), (a, b)
+        sims.append(d["sims"].cpu().numpy()); flags.append(d["flags"].cpu().numpy())
+    assert np.array_equal(np.concatenate(sims), ref["sims"]) and np.array_equal(np.concatenate(flags), ref["flags"])
+    fin = engine.drift_update(state, None, None, n * 4 + 3, 30)          # the final frame count alone changes the score's total
+    assert fin["score"] == oracle.drift_score(emb, valid, n * 4 + 3, 30)["score"] and fin["hits"] == ref["hits"]
+    whole = engine.drift_score(_t(emb), _t(valid), n * 4, 30)
+    assert whole["score"] == ref["score"] and ref["hits"] > 50
+
+
 def test_drift_score_long_clip_crosses_scan_chunks(engine, oracle):
     """The run-length scan stages similarities through LDS 4096 at a time: a 9,001-frame clip (three chunks, the last one
     ragged) with runs that straddle the chunk borders and faceless stretches must score exactly like the oracle."""

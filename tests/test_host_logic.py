@@ -436,21 +436,47 @@ def test_mjpeg_avi_sink_and_source(tmp_path):
 
 
 def test_run_cleans_up_when_analysis_fails(tmp_path, monkeypatch):
-    """An exception inside run()'s loop (a crowded frame -> TRL_ERR_CAPACITY, an allocation failure, ...) must not leave the
-    writer thread blocked on its queue or the files open: the long-lived service would leak both per failed request."""
+    """An exception inside run()'s loop (an allocation failure, a HIP error, a damaged clip ...) must not leave the reader or the
+    writer thread blocked on its queue or the files open: the long-lived service would leak them per failed request.  The real
+    run() loop and reader thread, with the device pieces (contexts, streams, pinned ring) replaced by host stand-ins."""
     import threading
-    from truely_amd import engine as eng_mod, model
+    from truely_amd import engine as eng_mod, model, pipeline
 
     class Boom(RuntimeError):
         pass
 
-    class FakeEngine:
-        def detect_embed(self, frames):
-            raise Boom("libtruely_hip status -4: candidate list overflow")
+    class FakeOverlapped:
+        def __init__(self, engines, **kw):
+            self.pushed = 0
 
-    fr = np.random.default_rng(2).integers(0, 255, (40, 24, 32, 3), dtype=np.uint8)
+        def push(self, batch):
+            self.pushed += 1
+            if self.pushed == 2:
+                raise Boom("libtruely_hip status -2: out of memory")
+
+        def finish(self):
+            return []
+
+        def abandon(self):
+            pass
+
+    class FakeCtx:
+        def __init__(self, eng):
+            self.engines, self.streams, self.lock = [eng, eng], [None, None], threading.Lock()
+
+        def buffers(self, rows, row_bytes, yuv, H, W):
+            bufs = [np.zeros((rows, row_bytes), np.uint8) for _ in range(4)]
+            return bufs, bufs, [np.zeros((rows, row_bytes), np.uint8) for _ in range(2)]
+
+    class FakeEngine:
+        device = None
+
+        def drift_state(self):
+            return None
+
+    fr = np.random.default_rng(2).integers(0, 255, (200, 24, 32, 3), dtype=np.uint8)
     src, dst = str(tmp_path / "in.trlv"), str(tmp_path / "out.trlv")
-    video_io.write_raw(src, fr, 7.0)                                    # fps 7 -> every frame sampled
+    video_io.write_raw(src, fr, 7.0)                                    # fps 7 -> every frame sampled: 32 per window
     released = []
     real_open = video_io.open_reader
 
@@ -460,17 +486,27 @@ def test_run_cleans_up_when_analysis_fails(tmp_path, monkeypatch):
         r[0].release = lambda: (released.append(path), rel())
         return r
 
+    fake = FakeEngine()
+    fake._run_ctx = FakeCtx(fake)
     monkeypatch.setattr(video_io, "open_reader", spy_open)
-    monkeypatch.setattr(eng_mod, "_default", FakeEngine())
+    monkeypatch.setattr(eng_mod, "_default", fake)
+    monkeypatch.setattr(model, "default_engine", lambda: fake)
+    monkeypatch.setattr(pipeline, "Overlapped", FakeOverlapped)
     before = {t.ident for t in threading.enumerate()}
     with pytest.raises(Boom):
         model.run(src, dst)
     assert released == [src]                                            # the reader was closed
-    left = [t for t in threading.enumerate() if t.ident not in before and t.name == "truely-writer" and t.is_alive()]
-    assert not left, "the writer thread survived the failed request"
+    left = [t for t in threading.enumerate() if t.ident not in before and t.name in ("truely-writer", "truely-reader") and t.is_alive()]
+    assert not left, f"threads survived the failed request: {left}"
     rd, _f, _w, _h = real_open(dst)                                     # the sink was closed properly (header patched)
     assert rd.n >= 0
     rd.release()
+    # ... and a clip that ends in the middle of a frame is analysed up to its last whole frame, not an error
+    with open(src, "r+b") as f:
+        f.truncate(32 + 24 * 32 * 3 * 50 + 100)
+    monkeypatch.setattr(pipeline, "Overlapped", lambda engines, **kw: type("Ok", (), {"push": lambda self, b: None, "finish": lambda self: [], "abandon": lambda self: None})())
+    fake.drift_update = lambda *a, **k: {"score": 0}
+    assert model.run(src, dst) == 0 and released == [src, src]
 
 
 def test_analysis_service_spreads_requests_over_gpus():

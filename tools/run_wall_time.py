@@ -1,14 +1,20 @@
-"""End-to-end wall time of the drop-in `run(video_path_one, video_path_two)` on BASELINE configs[0]'s shape -- the reference's only
-timing hook (server/model.py:15,78-80 prints "Total Execution Time" around the whole call: model construction, decode, analysis and
-re-encoding of every frame).  The reference's sample clip (test/*.mp4: 640x360, 30 fps, 960 frames, H.264) cannot be decoded without
-OpenCV, so the clip is 960 seeded synthetic frames of that shape in the raw TRLV container (BGR and NV12 variants).
+"""End-to-end wall time of the drop-in `run(video_path_one, video_path_two)` -- the reference's only timing hook
+(server/model.py:15,78-80 prints "Total Execution Time" around the whole call: model construction, decode, analysis and
+re-encoding of every frame).
 
-    python tools/run_wall_time.py [out.json]
+    python tools/run_wall_time.py [out.json] [--long]
 
-Reported per variant: the FIRST call of the process (engine construction + weight upload + workspace growth, which the reference
-pays on every call: model.py:18-19) and a warm call; with the annotated MJPEG/AVI output written and with the output stage skipped."""
+* BASELINE configs[0]'s shape: the reference's sample clip (test/*.mp4: 640x360, 30 fps, 960 frames, H.264) cannot be decoded
+  without OpenCV, so the clip is 960 seeded synthetic frames of that shape in the raw TRLV container (BGR and NV12) and as a
+  YUV4MPEG2 file (planar 4:2:0).  First call of the process (second context, pinned ring, workspace growth -- the reference
+  pays its model construction on every call: model.py:18-19), warm calls with the annotated MJPEG/AVI output written, and warm
+  calls with the output stage skipped (where only the sampled frames are read from the file at all).
+* --long: a 10-minute 720p clip (18,000 frames, 30 fps, 4,500 analysed) as NV12 TRLV and as YUV4MPEG2, output skipped, in
+  /dev/shm (25 GB each, written and deleted one after the other).
+Each line also carries the plain file-read rate of the same bytes into pinned memory (no GPU work): the bound of this path."""
 import json
 import os
+import shutil
 import sys
 import tempfile
 import time
@@ -21,40 +27,106 @@ from truely_amd import model, video_io  # noqa: E402
 from truely_amd.ingest import bgr_to_nv12  # noqa: E402
 
 
+def read_rate(path, step):
+    """Bytes of the sampled frames read with the same positioned reads into pinned memory, nothing else: GB/s and frames/s."""
+    import concurrent.futures
+    import torch
+    cap = video_io.open_reader(path)[0]
+    idx = list(range(0, cap.n, step))
+    buf = torch.empty((min(len(idx), 256), cap.frame_bytes), dtype=torch.uint8).pin_memory().numpy()
+    fd = cap.f.fileno()
+
+    def rd(a):
+        r, i = a
+        got, mv = 0, memoryview(buf[r % len(buf)])
+        while got < cap.frame_bytes:
+            got += os.preadv(fd, [mv[got:]], cap.frame_offset(i) + got)
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(4) as pool:
+        list(pool.map(rd, enumerate(idx)))
+    dt = time.perf_counter() - t0
+    cap.release()
+    return {"sampled_frames_per_s": round(len(idx) / dt, 1), "GB_per_s": round(len(idx) * cap.frame_bytes / dt / 1e9, 2)}
+
+
+def timed(label, src, dst, env, n_frames, step, repeat=1):
+    for k in ("TRUELY_WRITE_OUTPUT",):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    best = None
+    for _ in range(repeat):
+        t0 = time.perf_counter()
+        score = model.run(src, dst)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    size = os.path.getsize(dst) if os.path.exists(dst) and not env else None
+    if os.path.exists(dst):
+        os.remove(dst)
+    n_an = (n_frames + step - 1) // step
+    return {"what": label, "seconds": round(best, 4), "decoded_frames_per_s": round(n_frames / best, 1),
+            "analysed_frames_per_s": round(n_an / best, 1), "score": int(score), "output_bytes": size}
+
+
 def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
     H, W, fps, N = 360, 640, 30, 960
     uniq = truely_amd.synthetic.synthetic_frames(48, H, W, seed=21)           # 48 distinct frames, each held for 20 (0.67 s)
     res = {"clip": f"{N} frames {W}x{H} @ {fps} fps (BASELINE configs[0] shape, seeded synthetic frames), {N // 4} analysed",
            "reference_hook": "server/model.py:15,78-80 (Total Execution Time of run())", "runs": []}
     with tempfile.TemporaryDirectory() as td:
-        src_bgr, src_nv = os.path.join(td, "c0.trlv"), os.path.join(td, "c0_nv12.trlv")
+        src_bgr, src_nv, src_y4m = os.path.join(td, "c0.trlv"), os.path.join(td, "c0_nv12.trlv"), os.path.join(td, "c0.y4m")
         wr = video_io.RawWriter(src_bgr, fps, (W, H))
         wn = video_io.RawWriter(src_nv, fps, (W, H), "nv12")
         nv = bgr_to_nv12(uniq)
         for i in range(N):
             wr.write(uniq[i // 20]); wn.write(nv[i // 20])
         wr.release(); wn.release()
-        for label, src, env in (("first call: BGR clip, annotated output written", src_bgr, {}),
-                                ("warm: BGR clip, annotated output written", src_bgr, {}),
-                                ("warm: BGR clip, output stage skipped", src_bgr, {"TRUELY_WRITE_OUTPUT": "0"}),
-                                ("warm: NV12 clip (device ingest), annotated output written", src_nv, {}),
-                                ("warm: NV12 clip (device ingest), output stage skipped", src_nv, {"TRUELY_WRITE_OUTPUT": "0"})):
-            for k in ("TRUELY_WRITE_OUTPUT",):
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            dst = os.path.join(td, "out.avi")
-            t0 = time.perf_counter()
-            score = model.run(src, dst)
-            dt = time.perf_counter() - t0
-            size = os.path.getsize(dst) if os.path.exists(dst) and not env else None
-            res["runs"].append({"what": label, "seconds": round(dt, 3), "decoded_frames_per_s": round(N / dt, 1),
-                                "analysed_frames_per_s": round(N / 4 / dt, 1), "score": int(score), "output_bytes": size})
-            if os.path.exists(dst):
-                os.remove(dst)
+        video_io.write_y4m(src_y4m, nv[np.arange(N) // 20], fps, (W, H))
+        dst = os.path.join(td, "out.avi")
+        skip = {"TRUELY_WRITE_OUTPUT": "0"}
+        res["runs"].append(timed("first call: BGR clip, annotated output written", src_bgr, dst, {}, N, 4))
+        res["runs"].append(timed("warm: BGR clip, annotated output written", src_bgr, dst, {}, N, 4))
+        res["runs"].append(timed("first call without output: BGR clip (new window size: pinned ring re-allocated)", src_bgr, dst, skip, N, 4))
+        for label, src in (("BGR clip", src_bgr), ("NV12 clip (device ingest)", src_nv), ("YUV4MPEG2 clip (planar 4:2:0, device ingest)", src_y4m)):
+            r = timed(f"warm: {label}, output stage skipped (best of 5)", src, dst, skip, N, 4, repeat=5)
+            r["file_read_alone"] = read_rate(src, 4)
+            res["runs"].append(r)
+        res["runs"].append(timed("warm: NV12 clip (device ingest), annotated output written", src_nv, dst, {}, N, 4))
+    if "--long" in sys.argv:
+        H, W, N = 720, 1280, 18000
+        base = truely_amd.synthetic.synthetic_frames(16, H, W, seed=0)
+        nvb = bgr_to_nv12(base)
+        root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 40e9 else tempfile.gettempdir()
+        res["long_clip"] = f"{N} frames {W}x{H} @ {fps} fps = 10 minutes, {N // 4} analysed, 16 distinct frames each held for 8 then rolled; files in {root}"
+        for kind in ("nv12.trlv", "y4m"):
+            src = os.path.join(root, f"truely_long.{kind}")
+            try:
+                t0 = time.perf_counter()
+                if kind == "y4m":
+                    with open(src, "wb") as f:
+                        f.write(f"YUV4MPEG2 W{W} H{H} F{fps}:1 Ip A1:1 C420jpeg\n".encode())
+                        ys = H * W
+                        for i in range(N):
+                            fr = np.roll(nvb[(i // 8) % 16], 4 * (i // 128))
+                            f.write(b"FRAME\n"); f.write(fr[:ys].tobytes()); f.write(fr[ys::2].tobytes()); f.write(fr[ys + 1::2].tobytes())
+                else:
+                    w = video_io.RawWriter(src, fps, (W, H), "nv12")
+                    for i in range(N):
+                        w.write(np.roll(nvb[(i // 8) % 16], 4 * (i // 128)))
+                    w.release()
+                wrote = time.perf_counter() - t0
+                skip = {"TRUELY_WRITE_OUTPUT": "0"}
+                r = timed(f"10-minute 720p clip, {kind}, output stage skipped (second of two calls)", src, os.path.join(root, "truely_out.avi"), skip, N, 4, repeat=2)
+                r["file_bytes"] = os.path.getsize(src); r["file_written_in_s"] = round(wrote, 1)
+                r["file_read_alone"] = read_rate(src, 4)
+                res["runs"].append(r)
+            finally:
+                if os.path.exists(src):
+                    os.remove(src)
     line = json.dumps(res)
     print(line)
-    if len(sys.argv) > 1:
-        open(sys.argv[1], "w").write(line + "\n")
+    if args:
+        open(args[0], "w").write(line + "\n")
 
 
 if __name__ == "__main__":

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "trl_facenet_embed_masked": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "trl_drift_score": (C.c_int, [_vp, _vp, _vp, _i, C.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "trl_ingest_nv12": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
+    "trl_ingest_i420": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
+    "trl_drift_update": (C.c_int, [_vp, _vp, _vp, _vp, _i, C.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "trl_debug_stage_boxes": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "trl_debug_level_counts": (C.c_int, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
     "trl_debug_level_cands": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),

@@ -513,6 +513,19 @@ int trl_drift_score(trl_ctx* c, const float* d_emb, const uint8_t* d_valid, int 
     return trl_launch_drift(d_emb, d_valid, n, frame_count, fps, sims, d_flags, d_result, (hipStream_t)stream);
 }
 
+// trl_drift_score continued across the windows of ONE clip: d_state carries `previous embedding / run / hits` (model.py:60-75)
+int trl_drift_update(trl_ctx* c, void* d_state, const float* d_emb, const uint8_t* d_valid, int n, long long frame_count, int fps,
+                     float* d_sims, uint8_t* d_flags, int32_t* d_result, void* stream) {
+    if (!c || !d_state || !d_result || n < 0 || (n > 0 && (!d_emb || !d_valid)) || ((uintptr_t)d_state & 3)) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    TRL_HIP(hipSetDevice(c->cfg.device));
+    float* sims = d_sims;
+    if (!sims) {
+        TRL_CHECK(trl_ensure(c, c->sims_tmp, (size_t)(n > 0 ? n : 1) * sizeof(float)));
+        sims = (float*)c->sims_tmp.base;
+    }
+    return trl_launch_drift(d_emb, d_valid, n, frame_count, fps, sims, d_flags, d_result, (hipStream_t)stream, d_state);
+}
+
 // ---- inspection hooks ----------------------------------------------------------------------------------
 int trl_debug_stage_boxes(trl_ctx* c, int stage, int frame, float* h_boxes, int max_rows, int* n_out) {
     TRL_CHECK(check_idle(c));

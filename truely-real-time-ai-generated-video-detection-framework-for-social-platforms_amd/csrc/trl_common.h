@@ -152,7 +152,7 @@ int trl_launch_maxpool_bf16(const uint16_t* x, int N, int H, int W, int C, int l
 int trl_launch_gap_bf16(const uint16_t* x, int N, int HW, int C, float* y, hipStream_t s, int fmt = 1);
 int trl_launch_l2norm512(const float* x, const uint8_t* valid, int n, float* y, hipStream_t s);
 int trl_launch_drift(const float* emb, const uint8_t* valid, int n, long long frame_count, int fps,
-                     float* sims, uint8_t* flags, int32_t* result, hipStream_t s);
+                     float* sims, uint8_t* flags, int32_t* result, hipStream_t s, void* state = nullptr);
 
 static inline int trl_pool_out(int L, int k, int s, int ceil_mode) {
     int o;

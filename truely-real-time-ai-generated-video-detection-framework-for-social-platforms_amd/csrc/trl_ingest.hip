@@ -18,6 +18,9 @@ __device__ __forceinline__ unsigned sat8(int v) { return v < 0 ? 0u : (v > 255 ?
 
 struct __attribute__((packed, aligned(4))) u32x3 { unsigned x, y, z; };
 
+// PLANAR: the chroma follows the luma as two planes (I420: all U, then all V -- what YUV4MPEG2 files and software decoders
+// hold) instead of one interleaved plane (NV12: hardware decoders).  Same arithmetic, two 2-byte loads instead of one dword.
+template <bool PLANAR>
 __global__ __launch_bounds__(256) void k_nv12_to_bgr(const uint8_t* __restrict__ nv12, int n_out, int step, int H, int W,
                                                      uint8_t* __restrict__ bgr) {
     const int qw = W >> 2, qh = H >> 1;                       // 4x2-pixel quads per row / column
@@ -30,7 +33,14 @@ __global__ __launch_bounds__(256) void k_nv12_to_bgr(const uint8_t* __restrict__
         const uint8_t* src = nv12 + (size_t)j * step * frame_in;
         const unsigned y0 = *reinterpret_cast<const unsigned*>(src + (size_t)(2 * qy) * W + 4 * qx);
         const unsigned y1 = *reinterpret_cast<const unsigned*>(src + (size_t)(2 * qy + 1) * W + 4 * qx);
-        const unsigned uv = *reinterpret_cast<const unsigned*>(src + (size_t)H * W + (size_t)qy * W + 4 * qx);   // U0 V0 U1 V1
+        unsigned uv;                                                                                              // U0 V0 U1 V1
+        if (PLANAR) {
+            const unsigned u2 = *reinterpret_cast<const unsigned short*>(src + (size_t)H * W + (size_t)qy * (W >> 1) + 2 * qx);
+            const unsigned v2 = *reinterpret_cast<const unsigned short*>(src + (size_t)H * W + (size_t)(H >> 1) * (W >> 1) + (size_t)qy * (W >> 1) + 2 * qx);
+            uv = (u2 & 0xFF) | ((v2 & 0xFF) << 8) | ((u2 >> 8) << 16) | ((v2 >> 8) << 24);
+        } else {
+            uv = *reinterpret_cast<const unsigned*>(src + (size_t)H * W + (size_t)qy * W + 4 * qx);
+        }
         unsigned o[2][12];
 #pragma unroll
         for (int p = 0; p < 2; p++) {                          // two chroma samples, each covers 2x2 pixels
@@ -63,11 +73,10 @@ __global__ __launch_bounds__(256) void k_nv12_to_bgr(const uint8_t* __restrict__
 
 }  // namespace
 
-extern "C" int trl_ingest_nv12(trl_ctx* c, const uint8_t* d_nv12, int n_in, int H, int W, int step, uint8_t* d_bgr, int* n_out,
-                               void* stream) {
-    if (!c || !d_nv12 || !d_bgr || !n_out || n_in < 0 || step < 1) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
-    if ((W & 3) || (H & 1) || W < 4 || H < 2) { trl_set_error("NV12 ingest needs W %% 4 == 0 and even H (got %dx%d)", W, H); return TRL_ERR_INVALID; }
-    if (((uintptr_t)d_nv12 & 3) || ((uintptr_t)d_bgr & 3)) { trl_set_error("buffers must be 4-byte aligned"); return TRL_ERR_INVALID; }
+static int ingest_420(trl_ctx* c, const uint8_t* d_in, int n_in, int H, int W, int step, bool planar, uint8_t* d_bgr, int* n_out, void* stream) {
+    if (!c || !d_in || !d_bgr || !n_out || n_in < 0 || step < 1) { trl_set_error("bad argument"); return TRL_ERR_INVALID; }
+    if ((W & 3) || (H & 1) || W < 4 || H < 2) { trl_set_error("4:2:0 ingest needs W %% 4 == 0 and even H (got %dx%d)", W, H); return TRL_ERR_INVALID; }
+    if (((uintptr_t)d_in & 3) || ((uintptr_t)d_bgr & 3)) { trl_set_error("buffers must be 4-byte aligned"); return TRL_ERR_INVALID; }
     const int no = (n_in + step - 1) / step;                   // frames i with i % step == 0 (model.py:46)
     *n_out = no;
     if (no == 0) return TRL_OK;
@@ -75,7 +84,17 @@ extern "C" int trl_ingest_nv12(trl_ctx* c, const uint8_t* d_nv12, int n_in, int 
     const long long total = (long long)no * (H >> 1) * (W >> 2);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    k_nv12_to_bgr<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_nv12, no, step, H, W, d_bgr);
+    if (planar) k_nv12_to_bgr<true><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_in, no, step, H, W, d_bgr);
+    else k_nv12_to_bgr<false><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_in, no, step, H, W, d_bgr);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
+}
+
+extern "C" int trl_ingest_nv12(trl_ctx* c, const uint8_t* d_nv12, int n_in, int H, int W, int step, uint8_t* d_bgr, int* n_out,
+                               void* stream) {
+    return ingest_420(c, d_nv12, n_in, H, W, step, false, d_bgr, n_out, stream);
+}
+extern "C" int trl_ingest_i420(trl_ctx* c, const uint8_t* d_i420, int n_in, int H, int W, int step, uint8_t* d_bgr, int* n_out,
+                               void* stream) {
+    return ingest_420(c, d_i420, n_in, H, W, step, true, d_bgr, n_out, stream);
 }

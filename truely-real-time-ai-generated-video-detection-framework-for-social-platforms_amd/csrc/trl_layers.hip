@@ -813,10 +813,19 @@ __global__ __launch_bounds__(64) void l2norm512_kernel(const float* __restrict__
     for (int i = 0; i < 8; i++) o[lane + 64 * i] = v[lane + 64 * i] / nrm;
 }
 
+// Carry of the drift state machine between consecutive windows of one clip (trl_drift_update): what model.py's loop variables
+// `previous_embedding`, `consecutive_count` and `ai_detected_frames` hold between two sampled frames (model.py:60-75).
+struct DriftState {
+    float prev[512];                 // embedding of the last frame that had one (model.py:75)
+    int32_t has_prev, run, hits, pad;
+};
+static_assert(sizeof(DriftState) == TRL_DRIFT_STATE_BYTES, "drift state layout");
+
 // server/model.py:60-61 -- cosine similarity of every embedded frame with the previous embedded frame.
 // One wave per sampled frame; the three 512-long dots use the oracle's fixed lane order (trl_wave_dot512).
+// `st` (optional): the window continues a clip -- a frame with no embedded predecessor inside the window compares with st->prev.
 __global__ __launch_bounds__(256) void drift_sims_kernel(const float* __restrict__ emb, const uint8_t* __restrict__ valid, int n,
-                                                         float* __restrict__ sims) {
+                                                         float* __restrict__ sims, const DriftState* __restrict__ st) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -824,9 +833,9 @@ __global__ __launch_bounds__(256) void drift_sims_kernel(const float* __restrict
     if (valid[i]) {
         int prev = i - 1;
         while (prev >= 0 && !valid[prev]) prev--;   // frames without a face neither compare nor replace `previous` (model.py:48-75)
-        if (prev >= 0) {
+        const float* pv = prev >= 0 ? emb + (size_t)prev * 512 : ((st && st->has_prev) ? st->prev : nullptr);
+        if (pv) {
             const float* cur = emb + (size_t)i * 512;
-            const float* pv = emb + (size_t)prev * 512;
             const float d = trl_wave_dot512(cur, pv, lane);
             const float na = sqrtf(trl_wave_dot512(cur, cur, lane)), nb = sqrtf(trl_wave_dot512(pv, pv, lane));
             sim = d / (na * nb);
@@ -837,13 +846,18 @@ __global__ __launch_bounds__(256) void drift_sims_kernel(const float* __restrict
 
 // server/model.py:62-66,70,86-95 -- the run-length state machine is a scan over the similarities: staged in
 // LDS in chunks, walked by one lane, then the score in double like the reference's Python floats.
+// `st` (optional): counters start from the carried state, which then takes the window's final counters and last embedding.
 __global__ __launch_bounds__(256) void drift_scan_kernel(const float* __restrict__ sims, int n, long long frame_count, int fps,
-                                                         uint8_t* __restrict__ flags, int32_t* __restrict__ result) {
+                                                         uint8_t* __restrict__ flags, int32_t* __restrict__ result,
+                                                         DriftState* __restrict__ st, const float* __restrict__ emb,
+                                                         const uint8_t* __restrict__ valid) {
     __shared__ float sh[4096];
     __shared__ uint8_t fl[4096];
+    __shared__ int last_valid;
     const float thr_sim = 0.99f;   // model.py:16
     const int thr_frames = 15;     // model.py:17
-    int run = 0, hits = 0;
+    int run = st ? st->run : 0, hits = st ? st->hits : 0;
+    if (threadIdx.x == 0) last_valid = -1;
     for (int base = 0; base < n; base += 4096) {
         const int m = (n - base) < 4096 ? (n - base) : 4096;
         for (int t = threadIdx.x; t < m; t += blockDim.x) sh[t] = sims[base + t];
@@ -861,9 +875,16 @@ __global__ __launch_bounds__(256) void drift_scan_kernel(const float* __restrict
         }
         __syncthreads();
         if (flags) for (int t = threadIdx.x; t < m; t += blockDim.x) flags[base + t] = fl[t];
+        if (st) for (int t = threadIdx.x; t < m; t += blockDim.x) if (valid[base + t]) atomicMax(&last_valid, base + t);
         __syncthreads();
     }
+    if (st) {                               // (the similarities were computed by the previous kernel: st->prev is free to change)
+        __syncthreads();
+        const int lv = last_valid;
+        if (lv >= 0) for (int t = threadIdx.x; t < 512; t += blockDim.x) st->prev[t] = emb[(size_t)lv * 512 + t];
+    }
     if (threadIdx.x == 0) {
+        if (st) { st->run = run; st->hits = hits; if (last_valid >= 0) st->has_prev = 1; }
         int score = 0;
         long long total = 0;
         if (frame_count > 0 && fps > 0) {
@@ -962,12 +983,13 @@ int trl_launch_l2norm512(const float* x, const uint8_t* valid, int n, float* y, 
 }
 
 int trl_launch_drift(const float* emb, const uint8_t* valid, int n, long long frame_count, int fps, float* sims,
-                     uint8_t* flags, int32_t* result, hipStream_t s) {
+                     uint8_t* flags, int32_t* result, hipStream_t s, void* state) {
+    DriftState* st = (DriftState*)state;
     if (n > 0) {
-        drift_sims_kernel<<<(n + 3) / 4, 256, 0, s>>>(emb, valid, n, sims);
+        drift_sims_kernel<<<(n + 3) / 4, 256, 0, s>>>(emb, valid, n, sims, st);
         TRL_LAUNCH_CHECK();
     }
-    drift_scan_kernel<<<1, 256, 0, s>>>(sims, n, frame_count, fps, flags, result);
+    drift_scan_kernel<<<1, 256, 0, s>>>(sims, n, frame_count, fps, flags, result, st, emb, valid);
     TRL_LAUNCH_CHECK();
     return TRL_OK;
 }

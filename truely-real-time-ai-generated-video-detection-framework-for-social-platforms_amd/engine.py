@@ -64,6 +64,10 @@ class Engine:
                       embed_mode=c.embed_mode, embed_precision=c.embed_precision)
 
     def close(self):
+        for name in ("_embedder", "_run_ctx"):            # contexts / buffers cached on this engine by pipeline.Overlapped / model.run
+            o = self.__dict__.pop(name, None)
+            if o is not None and hasattr(o, "close"):
+                o.close()
         if getattr(self, "_h", None):
             self.lib.trl_destroy(self._h)
             self._h = None
@@ -189,7 +193,8 @@ class Engine:
         return emb
 
     # NV12 decoder output -> sampled BGR batch on the device (model.py:43,46)
-    def ingest_nv12(self, nv12, H: int, W: int, step: int) -> torch.Tensor:
+    def ingest_nv12(self, nv12, H: int, W: int, step: int, planar: bool = False) -> torch.Tensor:
+        """``planar``: the frames are I420 (Y, U, V planes) instead of NV12 (Y plane, interleaved UV)."""
         if isinstance(nv12, np.ndarray):
             nv12 = torch.from_numpy(np.ascontiguousarray(nv12))
         nv12 = nv12.to(self.device).contiguous()
@@ -199,7 +204,8 @@ class Engine:
         n_out = (n_in + step - 1) // step
         out = torch.empty((n_out, H, W, 3), dtype=torch.uint8, device=self.device)
         k = C.c_int()
-        _lib.check(self.lib.trl_ingest_nv12(self._h, _ptr(nv12), n_in, H, W, int(step), _ptr(out), C.byref(k), self._stream()))
+        fn = self.lib.trl_ingest_i420 if planar else self.lib.trl_ingest_nv12
+        _lib.check(fn(self._h, _ptr(nv12), n_in, H, W, int(step), _ptr(out), C.byref(k), self._stream()))
         assert k.value == n_out
         return out
 
@@ -215,6 +221,32 @@ class Engine:
                                             _ptr(res), self._stream()))
         r = res.cpu().tolist()
         return {"score": r[0], "run": r[1], "hits": r[2], "total": r[3], "sims": sims, "flags": flags}
+
+    DRIFT_STATE_BYTES = 2064
+
+    def drift_state(self) -> torch.Tensor:
+        """A fresh carry for :meth:`drift_update` (one per clip)."""
+        return torch.zeros((self.DRIFT_STATE_BYTES,), dtype=torch.uint8, device=self.device)
+
+    def drift_update(self, state: torch.Tensor, emb: torch.Tensor | None, valid: torch.Tensor | None, frame_count: int, fps: int,
+                     want_flags: bool = True, sync: bool = True):
+        """model.py:60-66 for the NEXT window of a clip (``trl_drift_update``): ``state`` carries previous embedding / run / hits.
+        ``emb`` = None (or empty): only the score for ``frame_count`` is recomputed.  ``sync=False`` returns device tensors only
+        (``result`` = [score, run, hits, total]) and does not wait."""
+        n = 0 if emb is None else int(emb.shape[0])
+        d = self.device
+        if n:
+            emb = emb.to(d, torch.float32).contiguous(); valid = valid.to(d, torch.uint8).contiguous()
+        sims = torch.empty((n,), dtype=torch.float32, device=d)
+        flags = torch.empty((n,), dtype=torch.uint8, device=d) if want_flags else None
+        res = torch.empty((4,), dtype=torch.int32, device=d)
+        _lib.check(self.lib.trl_drift_update(self._h, _ptr(state), _ptr(emb) if n else C.c_void_p(0), _ptr(valid) if n else C.c_void_p(0), n,
+                                             int(frame_count), int(fps), _ptr(sims), _ptr(flags), _ptr(res), self._stream()))
+        out = {"sims": sims, "flags": flags, "result": res}
+        if sync:
+            r = res.cpu().tolist()
+            out.update(score=r[0], run=r[1], hits=r[2], total=r[3])
+        return out
 
     # ---- inspection hooks (parity tests) ----
     def stage_boxes(self, stage: int, frame: int, max_rows: int | None = None) -> np.ndarray:

@@ -8,7 +8,6 @@ drift state machine (model.py:60-66), which consumes their embeddings in order.
 """
 from __future__ import annotations
 
-import os
 import queue
 import threading
 from typing import Callable, Iterable, List, Sequence
@@ -41,114 +40,153 @@ def detect_embed_grouped(engine: Engine, batches: Sequence, embed_group: int = 1
     return outs
 
 
-def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Callable[[int, dict], None] | None = None,
-                            streams=None, embed_group: int = 1, embed_engine: Engine | None = None, n_batches: int | None = None,
-                            on_detect: Callable[[int, int], None] | None = None) -> List[dict]:
-    """Batches in flight driven by ONE host thread.  Batch i is queued on ``engines[i % F]`` (``trl_detect_embed_begin`` /
-    ``trl_detect_crop_begin``: return without synchronising) on that engine's stream and finished (``trl_detect_embed_end``)
-    right before the engine is needed again, so F batches are in flight and no thread per context is needed.
+class Overlapped:
+    """Batches in flight driven by ONE host thread, as a stream: ``push(batch)`` queues the next batch, ``finish()`` drains.
+
+    Batch i is queued on ``engines[i % F]`` (``trl_detect_embed_begin`` / ``trl_detect_crop_begin``: return without synchronising)
+    on that engine's stream and finished (``trl_detect_embed_end``) right before the engine is needed again, so F batches are in
+    flight and no thread per context is needed.  The number of batches need not be known (``model.run`` streams a clip).
 
     ``embed_group`` = G > 1: the embedder is decoupled from the batches.  The cascades write their crops into consecutive slots
     of a ring; every G consecutive batches (in batch order, whichever engine produced them) are embedded by ONE
     ``trl_facenet_embed_masked`` call of ``embed_engine`` (a context of its own, created and cached on first use), queued behind
-    the cascade that produced the group's last batch.  InceptionResnetV1 at the reference's 80x80 crops is ~100 small dependent
-    launches whose fixed cost amortises over the faces of a call: 2.16 ms per 256 faces at 256 per call, 1.70 ms at 768, 1.60 ms
-    (47.6 % of the f32-MFMA peak) at 1,024.  Every output element is the same accumulation chain whatever the grouping: results
-    are bit-identical to per-batch ``detect_embed``.
+    the cascade that produced the group's last batch -- the position the embedder has inside a per-batch ``trl_detect_embed``.  (A
+    third stream of its own was measured in round 3: same throughput, but its ~100 small launches then interleave with BOTH
+    cascades' persistent PNet launches and stretch them, 7.1 -> 8.5 ms per launch.)  InceptionResnetV1 at the reference's 80x80
+    crops is ~100 small dependent launches whose fixed cost amortises over the faces of a call: 2.16 ms per 256 faces at 256 per
+    call, 1.60 ms at 1,024, 1.38 ms at 2,048.  Every output element is the same accumulation chain whatever the grouping:
+    results are bit-identical to per-batch ``detect_embed``.
 
-    If a call fails (a capacity overflow in a crowded batch, an allocation failure) the calls still queued on the other engines are
-    finished before the exception propagates, so every engine can be used again.
-
-    ``batches``: a sequence, or a callable ``(i, j) -> batch`` with ``n_batches`` (the bench's NV12 uploader prefetches per engine).
     ``on_detect(i, j)`` is called when batch i's cascade has finished on engine j (timing hooks); ``on_result(i, out)`` in batch
-    order once the batch's embeddings exist.  Returns the per-batch results in batch order."""
-    F = len(engines)
-    if F == 0:
-        raise ValueError("need at least one engine")
-    if callable(batches):
-        get, K = batches, int(n_batches)
-    else:
-        seq = list(batches)
-        get, K = (lambda i, j: seq[i]), len(seq)
-    G = max(1, int(embed_group))
-    dev = engines[0].device
-    streams = streams or [torch.cuda.Stream(dev) for _ in range(F)]
-    outs: List[dict] = []
-    inflight = [None] * F                                # batch index queued on engine j
+    order once the batch's embeddings exist (results arrive up to F + 2G batches after their push).  Delivered tensors are safe
+    to use on the caller's current stream.  If a call fails, ``abandon()`` (called by the wrappers on any exception) finishes
+    the calls still queued on the other engines, so every engine can be used again."""
 
-    def deliver(i, out):
-        if on_result:
-            on_result(i, out)
-        outs.append(out)
+    def __init__(self, engines: Sequence[Engine], on_result: Callable[[int, dict], None] | None = None, streams=None,
+                 embed_group: int = 1, embed_engine: Engine | None = None, on_detect: Callable[[int, int], None] | None = None,
+                 collect: bool = True):
+        self.engines = list(engines)
+        self.F = F = len(self.engines)
+        if F == 0:
+            raise ValueError("need at least one engine")
+        self.G = G = max(1, int(embed_group))
+        self.dev = self.engines[0].device
+        self.streams = streams or [torch.cuda.Stream(self.dev) for _ in range(F)]
+        self.on_result, self.on_detect, self.keep = on_result, on_detect, collect
+        self.outs: List[dict] = []
+        self.inflight = [None] * F                       # batch index queued on engine j
+        self.count = 0                                   # batches pushed
+        if G > 1:
+            emb_eng = embed_engine or getattr(self.engines[0], "_embedder", None)
+            if emb_eng is None:                          # its own context (its workspace must not alias a cascade's), built once
+                emb_eng = self.engines[0]._embedder = self.engines[0].clone()
+            if any(emb_eng is e for e in self.engines):
+                raise ValueError("embed_engine must be a context of its own: a cascade engine has a call in flight when the embedder runs")
+            self.emb_eng = emb_eng
+            self.S = 80 if self.engines[0].cfg.embed_mode == 0 else 160
+            self.R = G * ((2 * G + F + G - 1) // G)      # slots: F being written, G being collected, G being embedded; a multiple
+                                                         # of G so that a group never straddles the ring's end
+            self.ring = {"n": 0, "faces": None, "valid": None}
+            self.group: List[tuple] = []                 # (batch index, out) collected for the next embedder call, consecutive slots
+            self.pending: List[tuple] = []               # (event, emb, valid copy, [(i, out), ...]) embedder calls in flight, oldest first
+            self.last_embed = None                       # event behind the most recent embedder call
+            self.done: dict = {}                         # cascades finished out of batch order wait here
+            self.nxt = 0                                 # next batch index to join a group
 
-    def abandon():
+    # ---- common -------------------------------------------------------------------------------------------------------
+    def _deliver(self, i, out):
+        cur = torch.cuda.current_stream(self.dev)
+        for v in out.values():                           # allocated under another stream: tell the allocator who reads them now
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                v.record_stream(cur)
+        if self.on_result:
+            self.on_result(i, out)
+        if self.keep:
+            self.outs.append(out)
+
+    def abandon(self):
         """An exception is propagating: finish whatever is still queued so that no engine stays 'busy'."""
-        for j in range(F):
-            if inflight[j] is not None:
+        for j in range(self.F):
+            if self.inflight[j] is not None:
                 try:
-                    with torch.cuda.stream(streams[j]):
-                        engines[j].detect_embed_end()
+                    with torch.cuda.stream(self.streams[j]):
+                        self.engines[j].detect_embed_end()
                 except Exception:  # noqa: BLE001 - the first error is the one the caller sees
                     pass
-                inflight[j] = None
+                self.inflight[j] = None
+        if self.G > 1 and self.last_embed is not None:
+            self.last_embed.synchronize()                # the embedder's queued launches read the ring: let them end before it is freed
 
-    if G == 1:
-        def finish(j):
-            i, inflight[j] = inflight[j], None           # (whatever _end does, the call is over)
-            with torch.cuda.stream(streams[j]):
-                out = engines[j].detect_embed_end()      # synchronises stream j: the tensors are safe to use on any stream
-            if on_detect:
-                on_detect(i, j)
-            deliver(i, out)
+    def push(self, batch):
+        """Queue the next batch: a uint8 (n, H, W, 3) tensor / array, or a callable ``j -> batch`` evaluated under engine j's stream
+        (a source that queues device work of its own: the NV12 conversion)."""
+        i, j = self.count, self.count % self.F
+        self.count += 1
+        if self.inflight[j] is not None:
+            self._finish(j)
+            if self.G > 1:
+                self._collect(j)
+        if self.G > 1:
+            self._retire(block_for=i)
+        with torch.cuda.stream(self.streams[j]):
+            b = batch(j) if callable(batch) else batch
+            if self.G > 1:
+                fv, vv = self._slot_views(i, int(b.shape[0]))
+                self.engines[j].detect_embed_begin(b, crop=True, faces=fv, valid=vv)
+            else:
+                self.engines[j].detect_embed_begin(b)
+        self.inflight[j] = i
 
-        try:
-            for i in range(K):
-                j = i % F
-                if inflight[j] is not None:
-                    finish(j)
-                with torch.cuda.stream(streams[j]):
-                    engines[j].detect_embed_begin(get(i, j))
-                inflight[j] = i
-            for k in range(K, K + F):                    # drain in batch order
-                if inflight[k % F] is not None:
-                    finish(k % F)
-        except BaseException:
-            abandon()
-            raise
-        return outs
+    def finish(self) -> List[dict]:
+        """Drain: every pushed batch is finished, embedded and delivered (in batch order)."""
+        K, F = self.count, self.F
+        for k in range(K, K + F):
+            j = k % F
+            if self.inflight[j] is not None:
+                self._finish(j)
+                if self.G > 1:
+                    self._collect(j)
+        if self.G > 1:
+            self._flush_group((K - 1) % F if K else 0)
+            while self.pending:
+                self._retire(block_for=self.pending[0][3][0][0] + self.R)    # wait for the oldest call
+        return self.outs
 
-    # ---- decoupled, grouped embedder ----------------------------------------------------------------------------------
-    emb_eng = embed_engine or getattr(engines[0], "_embedder", None)
-    if emb_eng is None:                                  # its own context (its workspace must not alias a cascade's), built once
-        emb_eng = engines[0]._embedder = engines[0].clone()
-    # The embedder call of a group is queued on the stream of the engine that produced the group's LAST batch, i.e. behind that
-    # cascade and in front of that engine's next one -- the position the embedder has inside a per-batch trl_detect_embed.  (A
-    # third stream of its own was measured: same throughput, but its ~100 small launches then interleave with BOTH cascades'
-    # persistent PNet launches and stretch them, 7.1 -> 8.5 ms per launch.)
-    S = 80 if engines[0].cfg.embed_mode == 0 else 160
-    R = G * ((2 * G + F + G - 1) // G)                   # slots: F being written, G being collected, G being embedded; a multiple
-                                                         # of G so that a group never straddles the ring's end
-    ring = {"n": 0, "faces": None, "valid": None}
-    group: List[tuple] = []                              # (batch index, out) collected for the next embedder call, consecutive slots
-    pending: List[tuple] = []                            # (event, emb, [(i, out), ...]) embedder calls in flight, oldest first
+    def _finish(self, j):
+        i, self.inflight[j] = self.inflight[j], None     # (whatever _end does, the call is over)
+        with torch.cuda.stream(self.streams[j]):
+            out = self.engines[j].detect_embed_end()     # synchronises stream j
+        if self.on_detect:
+            self.on_detect(i, j)
+        if self.G > 1:
+            self.done[i] = out
+        else:
+            self._deliver(i, out)
 
-    def slot_views(i, n):
+    # ---- decoupled, grouped embedder ------------------------------------------------------------------------------------
+    def _slot_views(self, i, n):
+        ring = self.ring
         if ring["faces"] is None:
+            need = self.R * n * (self.S * self.S * 3 * 4 + 1)
+            free, _total = torch.cuda.mem_get_info(self.dev)
+            if need > free // 2:
+                raise RuntimeError(f"the crop ring of embed_group={self.G} needs {need >> 20} MiB ({self.R} slots of {n} crops), "
+                                   f"{free >> 20} MiB are free: lower embed_group or the batch size")
             ring["n"] = n
-            with torch.cuda.stream(torch.cuda.default_stream(dev)):     # shared by every stream of the run: not owned by one of them
-                ring["faces"] = torch.empty((R, n, S, S, 3), dtype=torch.float32, device=dev)
-                ring["valid"] = torch.empty((R, n), dtype=torch.uint8, device=dev)
+            with torch.cuda.stream(torch.cuda.default_stream(self.dev)):     # shared by every stream of the run: not owned by one of them
+                ring["faces"] = torch.empty((self.R, n, self.S, self.S, 3), dtype=torch.float32, device=self.dev)
+                ring["valid"] = torch.empty((self.R, n), dtype=torch.uint8, device=self.dev)
         if n > ring["n"]:
             raise ValueError("batches must not grow after the first one")
-        k = i % R
+        k = i % self.R
         return ring["faces"][k, :n], ring["valid"][k, :n]
 
-    def retire(block_for: int | None = None):
+    def _retire(self, block_for: int | None = None):
         """Deliver finished embedder calls (oldest first); with ``block_for`` = a batch index, wait for every call that still
         reads the ring slot that batch is about to overwrite."""
-        while pending:
-            ev, emb, members = pending[0]
-            must = block_for is not None and members[0][0] <= block_for - R
+        while self.pending:
+            ev, emb, valid, members = self.pending[0]
+            must = block_for is not None and members[0][0] <= block_for - self.R
             if not (must or ev.query()):
                 break
             ev.synchronize()
@@ -156,95 +194,69 @@ def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Calla
             for i, out in members:
                 n = out["valid"].shape[0]
                 out["emb"] = emb[o:o + n]
+                out["valid"] = valid[o:o + n]            # the copy made behind the embedder call (the ring slot is reused)
                 o += n
-                out["valid"] = out["valid"].clone()      # the ring slot is reused
                 del out["faces"]
-                deliver(i, out)
-            pending.pop(0)
+                self._deliver(i, out)
+            self.pending.pop(0)
 
-    own = os.environ.get("TRUELY_EMBED_STREAM", "producer")      # experiment: "own" / "own_low" = a third stream (low priority)
-    own_stream = None
-    if own != "producer":
-        lo, hi = -1, 0
-        try:
-            lo, hi = torch.cuda.Stream.priority_range()
-        except Exception:  # noqa: BLE001
-            pass
-        own_stream = torch.cuda.Stream(dev, priority=max(lo, hi)) if own == "own_low" else torch.cuda.Stream(dev)
-
-    last_embed = [None]                                  # event behind the most recent embedder call
-
-    def flush_group(j):
+    def _flush_group(self, j):
+        group = self.group
         if not group:
             return
-        es = own_stream or streams[j]
-        i0, n_full = group[0][0], ring["n"]
+        es = self.streams[j]
+        i0, n_full, R, S = group[0][0], self.ring["n"], self.R, self.S
         k0 = i0 % R
         cnt = sum(out["valid"].shape[0] for _, out in group)
         if len(group) == 1:
             faces, valid = group[0][1]["faces"], group[0][1]["valid"]
         else:                                            # consecutive full slots (+ an optional short last one): one contiguous view
-            faces = ring["faces"].view(R * n_full, S, S, 3)[k0 * n_full:k0 * n_full + cnt]
-            valid = ring["valid"].view(R * n_full)[k0 * n_full:k0 * n_full + cnt]
+            faces = self.ring["faces"].view(R * n_full, S, S, 3)[k0 * n_full:k0 * n_full + cnt]
+            valid = self.ring["valid"].view(R * n_full)[k0 * n_full:k0 * n_full + cnt]
         with torch.cuda.stream(es):                      # the crops are complete: their cascades were synchronised by _end
-            if last_embed[0] is not None:
-                es.wait_event(last_embed[0])             # the embedder context has ONE workspace: its calls run one after the
+            if self.last_embed is not None:
+                es.wait_event(self.last_embed)           # the embedder context has ONE workspace: its calls run one after the
                                                          # other even when consecutive groups end on different engines' streams
-            emb = emb_eng.embed_faces(faces, valid)      # queues ~100 launches and returns
-            ev = torch.cuda.Event()
+            emb = self.emb_eng.embed_faces(faces, valid) # queues ~100 launches and returns
+            vcopy = valid.clone()                        # behind the embedder, in front of the event: ordered against the
+            ev = torch.cuda.Event()                      # cascade that will overwrite the slot (it waits for this event's call)
             ev.record(es)
-        last_embed[0] = ev
-        pending.append((ev, emb, list(group)))
+        self.last_embed = ev
+        self.pending.append((ev, emb, vcopy, list(group)))
         group.clear()
 
-    def finish(j):
-        i, inflight[j] = inflight[j], None
-        with torch.cuda.stream(streams[j]):
-            out = engines[j].detect_embed_end()
-        if on_detect:
-            on_detect(i, j)
-        done[i] = out
-
-    done: dict = {}                                      # cascades finished out of batch order wait here
-    nxt = [0]                                            # next batch index to join a group
-
-    def collect(j):
-        while nxt[0] in done:
-            i = nxt[0]
-            out = done.pop(i)
+    def _collect(self, j):
+        while self.nxt in self.done:
+            i = self.nxt
+            out = self.done.pop(i)
             n = out["valid"].shape[0]
-            group.append((i, out))
-            nxt[0] += 1
-            short = n < ring["n"]
-            wraps = (i + 1) % R == 0                     # the next slot is not adjacent in memory
-            if len(group) == G or short or wraps or i == K - 1:
-                flush_group(j)
+            self.group.append((i, out))
+            self.nxt += 1
+            short = n < self.ring["n"]
+            wraps = (i + 1) % self.R == 0                # the next slot is not adjacent in memory
+            if len(self.group) == self.G or short or wraps:
+                self._flush_group(j)
 
+
+def detect_embed_overlapped(engines: Sequence[Engine], batches, on_result: Callable[[int, dict], None] | None = None,
+                            streams=None, embed_group: int = 1, embed_engine: Engine | None = None, n_batches: int | None = None,
+                            on_detect: Callable[[int, int], None] | None = None) -> List[dict]:
+    """:class:`Overlapped` over a known list of batches.  ``batches``: a sequence, or a callable ``(i, j) -> batch`` with
+    ``n_batches`` (the bench's NV12 uploader prefetches per engine).  Returns the per-batch results in batch order.  If a call
+    fails, the calls still queued on the other engines are finished before the exception propagates."""
+    if callable(batches):
+        get, K = batches, int(n_batches)
+    else:
+        seq = list(batches)
+        get, K = (lambda i, j: seq[i]), len(seq)
+    ov = Overlapped(engines, on_result=on_result, streams=streams, embed_group=embed_group, embed_engine=embed_engine, on_detect=on_detect)
     try:
         for i in range(K):
-            j = i % F
-            if inflight[j] is not None:
-                finish(j)
-                collect(j)
-            retire(block_for=i)
-            with torch.cuda.stream(streams[j]):          # (the batch source may queue work of its own: NV12 conversion)
-                b = get(i, j)
-                fv, vv = slot_views(i, int(b.shape[0]))
-                engines[j].detect_embed_begin(b, crop=True, faces=fv, valid=vv)
-            inflight[j] = i
-        for k in range(K, K + F):
-            if inflight[k % F] is not None:
-                finish(k % F)
-                collect(k % F)
-        flush_group((K - 1) % F if K else 0)
-        while pending:
-            retire(block_for=pending[0][2][0][0] + R)    # wait for the oldest call
+            ov.push(lambda j, i=i: get(i, j))
+        return ov.finish()
     except BaseException:
-        abandon()
-        if last_embed[0] is not None:
-            last_embed[0].synchronize()                  # the embedder's queued launches read the ring: let them end before it is freed
+        ov.abandon()
         raise
-    return outs
 
 
 def detect_embed_pipelined(engines: Sequence[Engine], batches: Iterable, on_result: Callable[[int, dict], None] | None = None,

@@ -47,6 +47,13 @@ class RawReader:
         self.pixfmt = "nv12" if fmt == 1 else "bgr"
         self.frame_bytes = self.height * self.width * 3 // (2 if fmt == 1 else 1)
         self.i = 0
+        self.data0, self.stride = 32, self.frame_bytes    # random access (model.run's reader reads only what it needs, in parallel)
+        self.raw_pixfmt = self.pixfmt                     # layout of the bytes at frame_offset()
+        avail = max(0, (os.path.getsize(path) - 32) // self.frame_bytes) if self.frame_bytes else 0
+        self.n = min(self.n, avail)                       # a truncated file ends where its bytes end
+
+    def frame_offset(self, i: int) -> int:
+        return self.data0 + i * self.stride
 
     def isOpened(self):
         return True
@@ -103,6 +110,19 @@ class Y4MReader:
         self.frame_bytes = self.ysize + 2 * self.csize
         self.n = max(0, (os.path.getsize(path) - self.header) // (6 + self.frame_bytes))   # "FRAME\n" + planes (no frame params)
         self.i = 0
+        # random access to the planar frames as stored (I420: the device ingest takes them without repacking).  Only when every
+        # frame header is the bare "FRAME\n" (checked on the first two); otherwise model.run falls back to sequential read()
+        self.data0, self.stride, self.raw_pixfmt = self.header + 6, 6 + self.frame_bytes, "i420"
+        ok = True
+        for k in range(min(self.n, 2)):
+            self.f.seek(self.header + k * self.stride)
+            ok = ok and self.f.read(6) == b"FRAME\n"
+        self.f.seek(self.header)
+        if not ok:
+            self.stride = 0
+
+    def frame_offset(self, i: int) -> int:
+        return self.data0 + i * self.stride
 
     def isOpened(self):
         return True
