@@ -182,8 +182,11 @@ def parse_args(argv=None):
                     help="resident (the metric: frames already in HBM) or nv12 (supplementary: pinned host NV12 -> H2D -> "
                          "k_nv12_to_bgr -> the same path, PCIe inclusive)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo to rehearse N>1 on one GPU")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="batches in flight per GPU: each gets its own context, HIP stream and host thread; 1 = strictly sequential")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="batches in flight per GPU (each gets its own context and HIP stream).  1 (default): strictly sequential on "
+                         "the device, every kernel runs alone and the HIP event pair around a launch is its duration.  2: +3 %% "
+                         "frames/s (the head of one persistent PNet launch fills the tail of the other's), but then the pair also "
+                         "counts the wait behind the other context's launch (profiles/round4_pnet_gate_ab.txt)")
     ap.add_argument("--embed-group", type=int, default=8,
                     help="consecutive steps whose crops the decoupled embedder embeds in ONE InceptionResnetV1 call (trl_detect_crop per "
                          "step into a ring, then one trl_facenet_embed_masked): same bits, ~100 small launches amortised over G x 256 faces")
@@ -267,8 +270,6 @@ def main():
     blob = truely_amd.weights.pack_state_dicts(*sds)
     F = max(1, args.in_flight)
     ekw = dict(device=local, pnet_mode=args.pnet_mode, min_face_size=cfg["min_face"], embed_precision=cfg["embed"])
-    if cfg["H"] > 1080:
-        ekw.update(cap_level=3072, cap_frame=3072)
     engs = [Engine(blob, **ekw) for _ in range(F)]   # one context + workspace per batch in flight
     streams = [torch.cuda.Stream(dev) for _ in range(F)]
     eng = engs[0]
@@ -400,15 +401,11 @@ def main():
     if args.warmup > 0:
         run_steps(max(args.warmup, F))
     fence()
-    for e in engs:
-        e.pnet_span(reset=True)          # device-side sums of the fused PNet launches' execution spans: zeroed, read once after the region
     t0 = time.perf_counter()
     (out, d), acc = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     pnet_ms, pyr_ms = acc["pnet_ms"], acc["pyramid_ms"]
-    spans = [e.pnet_span() for e in engs]
-    pnet_kernel_ms, span_launches = sum(m for m, _ in spans), sum(k for _, k in spans)
     if use_dist:
         tdev = dev if args.backend == "nccl" else torch.device("cpu")
         tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
@@ -420,8 +417,8 @@ def main():
         scores = [int(d["score"])]
 
     # After the timed region (never part of `value`): the dominant kernel alone -- a few strictly sequential steps on one context,
-    # nothing else queued on the GPU -- so the line also carries the launch duration free of the queueing that two cascades in
-    # flight add to the event pair above (the committed `--in-flight 1` rocprofv3 stats show the same number).
+    # nothing else queued on the GPU -- as a cross-check of the figure above (with --in-flight 2 it is the launch duration free of
+    # the queueing behind the other context's launch).
     iso_ms = None
     if rank == 0 and eng.cfg.pnet_mode == 0 and frames is not None:
         torch.cuda.synchronize()
@@ -435,13 +432,12 @@ def main():
         tm = eng.timings()
         macs = pnet_macs(H, W, cfg["min_face"]) * n                  # per launch set of one step on this rank
         launches = max(1, tm["pnet_launches"])
-        # Duration of the dominant kernel per step, live over the timed region: the launch's EXECUTION SPAN on the device wall clock
-        # (first workgroup start to last workgroup end, stamped by the kernel itself and summed on the device) -- the quantity
-        # rocprofv3 reports as the kernel's duration, so the line and the committed kernel stats of the same command agree.  The
-        # HIP-event pair around the launch is reported next to it: with two batches in flight it also counts the time the launch
-        # waits behind the other context's kernels for CUs (the persistent grid needs every CU's registers).
-        use_span = pnet_kernel_ms > 0 and span_launches == args.steps * max(1, tm["pnet_launches"])
-        pnet_s = (pnet_kernel_ms if use_span else pnet_ms) / 1e3 / args.steps
+        # Duration of the dominant kernel per step, live over the timed region: the HIP event pair around every fused launch, on the
+        # stream it is launched on, summed over the region's steps.  Fused launches of the contexts in flight are ordered one
+        # after the other on the device (trl_pnet.hip: the persistent grid fills every CU), so the pair times the launch's
+        # execution -- the duration rocprofv3 reports for the same command (profiles/round4_bench_kernel_stats.csv) -- and not
+        # the wait behind the other context's launch.
+        pnet_s = pnet_ms / 1e3 / args.steps
         achieved = 2.0 * macs / pnet_s / 1e12
         traffic = None
         tpaths = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pnet_traffic.json"))
@@ -474,8 +470,7 @@ def main():
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "kernel": "k_pnet_fused (PNet over the pyramid: 83% of the conv FLOPs at 720p)",
                          "flop_per_step": 2.0 * macs, "kernel_ms_per_step": round(pnet_s * 1e3, 3), "launches_per_step": launches,
-                         "kernel_clock": "device wall clock: first workgroup start to last workgroup end of every launch in the timed region (= rocprofv3's duration)" if use_span else "HIP events",
-                         "kernel_ms_per_step_hip_events": round(pnet_ms / args.steps, 3),
+                         "kernel_clock": "HIP event pair around each launch on its stream, summed over the timed region",
                          "kernel_ms_alone": None if iso_ms is None else round(iso_ms, 3),
                          "frac_alone": None if iso_ms is None else round(2.0 * macs / (iso_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                          "pyramid_ms_per_step": round(pyr_ms / args.steps, 3)},

@@ -182,6 +182,11 @@ int  trl_debug_nms_tiers(trl_ctx* ctx, int small_tier, int full_tier);
  * available, rows per frame of the stage lists, record slots per frame over all levels, largest per-level candidate count,
  * largest per-frame stage-1 total} (ABI v7) */
 int  trl_debug_list_stats(trl_ctx* ctx, long long* h_out8);
+/* test hooks that used to be environment variables (the library reads none; experiment switches exist only in a `make TUNING=1`
+ * build): key "rnet_chunk" / "onet_chunk" = candidates per R-/O-Net launch set of this context (>= 16: small inputs then run
+ * the multi-chunk path); "no_fnconv" (process-wide, ctx may be NULL) = FaceNet's small maps through the generic conv kernels,
+ * value 0 restores the default.  Results never depend on them. (ABI v7) */
+int  trl_debug_option(trl_ctx* ctx, const char* key, int value);
 /* test hook: the R-/O-Net launches are sized by optimistic per-frame candidate capacities; set them (<= 0 keeps a value) and read
  * how many attempts the last call took (a too-small capacity makes the call re-run itself with a larger one) */
 int  trl_debug_batch_capacity(trl_ctx* ctx, float t2_per_frame, float t3_per_frame, int* last_attempts);
@@ -217,13 +222,13 @@ int  trl_debug_stage_totals(trl_ctx* ctx, int32_t* h_out2);
  * per cursor fetch (0 = automatic: 24 for large batches, down to 1 for small ones).  With runs > 1 a tile reuses the halo columns /
  * rows its left / upper neighbour computed; same results. */
 int  trl_debug_pnet_run(trl_ctx* ctx, int run);
-/* execution span (first workgroup start -> last workgroup end, device wall clock) of the last fused PNet launch, in ms:
- * the kernel's duration as rocprofv3 reports it, free of stream-queueing time when several contexts share the GPU */
+/* TUNING builds only (0 otherwise): execution span (first workgroup start -> last workgroup end, device wall clock) of the last
+ * fused PNet launch, in ms */
 int  trl_debug_pnet_kernel_ms(trl_ctx* ctx, float* ms);
-/* the same span summed on the device over every fused PNet launch of this context since the last reset (no per-call host
- * round trip: two atomics per workgroup and a one-thread kernel per launch): *ms_sum milliseconds over *launches launches.
- * Blocks until the device has finished the context's queued work only insofar as hipMemcpy does; bench.py reads it once,
- * after its timed region. (ABI v6) */
+/* TUNING builds with TRL_PNET_SPAN set only (0 launches otherwise): the same span summed on the device over every fused PNet
+ * launch of this context since the last reset.  The context must be idle.  The shipped library times the launch with the HIP
+ * event pair on its stream (trl_debug_timings out[0]); fused launches of different contexts on one device are ordered one after
+ * the other, so that pair measures execution, not queueing. (ABI v6) */
 int  trl_debug_pnet_span(trl_ctx* ctx, int reset, double* ms_sum, int32_t* launches);
 
 #ifdef __cplusplus

@@ -521,9 +521,7 @@ def test_large_embedder_batches_cross_kernel_families(engine, oracle):
     """ONE embedder call over more than 335 faces at 80x80 pushes block35's GEMMs past M = 16384 rows: the small-map family
     (fn_conv, 16x16x4 MFMA, grouped launches) hands over to the generic conv_tap kernels (32x32x2 MFMA).  bench.py's grouped
     embedder (768 faces per call) runs exactly that.  The embeddings must be the bits of 256-face calls and of the oracle --
-    and again with the small-map family switched off altogether (TRL_NO_FNCONV=1, a fresh process: the switch is read once)."""
-    import subprocess
-    import sys
+    and again with the small-map family switched off altogether (trl_debug_option "no_fnconv")."""
     fr = truely_amd.synthetic.synthetic_frames(8, 360, 640, seed=11)
     c = engine.detect_crop(fr)
     v = c["valid"].bool()
@@ -542,16 +540,12 @@ def test_large_embedder_batches_cross_kernel_families(engine, oracle):
     idx = [0, 1, 199, 200, 336, 398]
     ref = oracle.facenet(faces[idx].cpu().numpy())
     assert np.array_equal(big[idx].cpu().numpy(), ref)
-    np.save("/tmp/_trl_faces400.npy", faces.cpu().numpy())
-    np.save("/tmp/_trl_emb400.npy", big.cpu().numpy())
-    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import truely_amd; from truely_amd.engine import Engine; "
-            "e = Engine(truely_amd.weights.synthetic_blob(0)); f = torch.from_numpy(np.load('/tmp/_trl_faces400.npy')); "
-            "v = torch.ones(400, dtype=torch.uint8); v[[3, 77, 399]] = 0; "
-            "g = e.embed_faces(f, v).cpu().numpy(); assert np.array_equal(g, np.load('/tmp/_trl_emb400.npy')); print('same')"
-            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, TRL_NO_FNCONV="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
+    engine.option("no_fnconv", 1)                        # the small-map family switched off: every layer through conv_tap / conv_igemm
+    try:
+        again = engine.embed_faces(faces, valid)
+    finally:
+        engine.option("no_fnconv", 0)
+    assert torch.equal(again, big)
 
 
 def test_overlapped_pipeline_recovers_from_a_failed_call(blob):

@@ -605,29 +605,14 @@ def test_batch_capacity_overflow_reruns_the_call(blob, oracle):
     assert (rb is None and k0 == 0) or np.array_equal(b[0, :k0].cpu().numpy(), rb)
 
 
-def test_multi_chunk_candidate_batches():
+def test_multi_chunk_candidate_batches(blob, oracle):
     """R-/O-Net candidate batches larger than one launch set are processed in chunks (device-side `total - chunk_base` clamps).
-    With the chunk sizes shrunk to 16 / 16 candidates (fresh process: they are read once) a 360p clip needs many chunks, some of
-    them partially filled, some empty -- results must not change."""
-    import subprocess, sys, os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import numpy as np, truely_amd\n"
-        "from truely_amd.engine import Engine\n"
-        "from oracle.oracle import Oracle\n"
-        "blob = truely_amd.weights.synthetic_blob(0)\n"
-        "eng, orc = Engine(blob), Oracle(blob)\n"
-        "fr = truely_amd.synthetic.synthetic_frames(3, 360, 640, seed=11)\n"
-        "out, ref = eng.detect_embed(fr), orc.detect_embed(fr)\n"
-        "assert sum(eng.stage_boxes(1, i).shape[0] for i in range(3)) > 48    # several 16-candidate chunks, the last one ragged\n"
-        "for k in ('box', 'prob', 'rect', 'valid', 'emb'):\n"
-        "    assert np.array_equal(out[k].cpu().numpy(), ref[k]), k\n"
-        "for i in range(3):\n"
-        "    tr = orc.detect(fr[i], trace=True)[2]\n"
-        "    for s in (1, 2, 3):\n"
-        "        assert np.array_equal(eng.stage_boxes(s, i), tr['boxes%%d' %% s]), (i, s)\n"
-        "print('chunks ok')\n" % (root, os.path.join(root, "tests")))
-    env = dict(os.environ, TRL_RNET_CHUNK="16", TRL_ONET_CHUNK="16")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert p.returncode == 0 and "chunks ok" in p.stdout, p.stderr[-2000:]
+    With the chunk sizes shrunk to 16 / 16 candidates (trl_debug_option) a 360p clip needs many chunks, some of them partially
+    filled, some empty -- results must not change."""
+    from truely_amd.engine import Engine
+    eng = Engine(blob)
+    eng.option("rnet_chunk", 16)
+    eng.option("onet_chunk", 16)
+    fr = truely_amd.synthetic.synthetic_frames(3, 360, 640, seed=11)
+    _check_cascade(eng, oracle, fr)
+    assert sum(eng.stage_boxes(1, i).shape[0] for i in range(3)) > 48    # several 16-candidate chunks, the last one ragged

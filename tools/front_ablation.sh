@@ -3,6 +3,7 @@
 # 2 = R-Net conv, 4 = O-Net crop, 8 = O-Net conv): timing-only ablations under rocprofv3, run on the GPU box:
 #   gpurun -- 'bash tools/front_ablation.sh'    -> gpurun_out/front_ablation.txt
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export TRUELY_HIP_LIB="$GRAFT_REPO_ROOT/truely-real-time-ai-generated-video-detection-framework-for-social-platforms_amd/libtruely_hip_tuning.so"   # the TRL_* switches exist in the tuning build only (make -C .../csrc TUNING=1)
 O=gpurun_out/front_ablation
 rm -rf $O && mkdir -p $O
 : > gpurun_out/front_ablation.txt

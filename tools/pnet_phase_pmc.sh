@@ -3,6 +3,7 @@
 # 4 = conv2, 8 = conv3+heads+candidates, 32 = emit no candidates -- set in every run so that garbage maps cannot overflow the lists;
 # timing-only ablations).  gpurun -- 'bash tools/pnet_phase_pmc.sh'
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export TRUELY_HIP_LIB="$GRAFT_REPO_ROOT/truely-real-time-ai-generated-video-detection-framework-for-social-platforms_amd/libtruely_hip_tuning.so"   # the TRL_* switches exist in the tuning build only (make -C .../csrc TUNING=1)
 O=gpurun_out/pnet_phase
 rm -rf $O && mkdir -p $O
 : > gpurun_out/pnet_phase_pmc.txt

@@ -7,6 +7,7 @@
 # another context's; the headline bench keeps the default two.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh
+TUNE_LIB="$GRAFT_REPO_ROOT/truely-real-time-ai-generated-video-detection-framework-for-social-platforms_amd/libtruely_hip_tuning.so"   # TRL_* switches: tuning build only
 rm -rf $O && mkdir -p $O
 B="--no-cpu-baseline"
 timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench done"; cut -c1-300 $O/bench.json
@@ -22,7 +23,7 @@ timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --driver thr
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --embed-group 1 > $O/bench_embed_group1.json 2> $O/bench_embed_group1.err
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --embed-group 4 > $O/bench_embed_group4.json 2> $O/bench_embed_group4.err
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --in-flight 1 --embed-group 1 > $O/bench_inflight1_group1.json 2> $O/bench_inflight1_group1.err
-TRL_PNET_RUN=1 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --in-flight 1 --embed-group 1 > $O/bench_inflight1_group1_nocarry.json 2> $O/bench_inflight1_group1_nocarry.err
+TRUELY_HIP_LIB=$TUNE_LIB TRL_PNET_RUN=1 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 $B --in-flight 1 --embed-group 1 > $O/bench_inflight1_group1_nocarry.json 2> $O/bench_inflight1_group1_nocarry.err
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --mode streams --ingest nv12 --steps 6 $B > $O/bench_gloo2_streams_nv12.json 2> $O/bench_gloo2_streams_nv12.err
 timeout -k 10 300 python bench.py --ingest nv12 --steps 10 $B > $O/bench_ingest_nv12.json 2> $O/bench_ingest_nv12.err
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --steps 6 $B > $O/bench_gloo2_sharded.json 2> $O/bench_gloo2_sharded.err
@@ -47,7 +48,7 @@ timeout -k 10 200 python tools/fn_stamps.py 2 5 16 58 60 61 2>&1 | grep -E "laun
 echo "facenet done"
 # where the waves of the fused PNet kernel spend their time (DBG instantiation: shader clocks per phase and barrier), its phase
 # ablation with SQ counters, and the batch sweeps
-TRL_PNET_CLOCK=1 timeout -k 10 300 python bench.py --steps 10 --warmup 2 $B --in-flight 1 --embed-group 1 > $O/bench_pnet_clock.json 2> $O/pnet_clock.err; grep TRL_PNET_CLOCK $O/pnet_clock.err > $O/pnet_phase_clocks.txt
+TRUELY_HIP_LIB=$TUNE_LIB TRL_PNET_CLOCK=1 timeout -k 10 300 python bench.py --steps 10 --warmup 2 $B --in-flight 1 --embed-group 1 > $O/bench_pnet_clock.json 2> $O/pnet_clock.err; grep TRL_PNET_CLOCK $O/pnet_clock.err > $O/pnet_phase_clocks.txt
 bash tools/pnet_phase_pmc.sh > /dev/null 2>&1; cp gpurun_out/pnet_phase_pmc.txt $O/pnet_phase_pmc.txt
 bash tools/front_ablation.sh > /dev/null 2>&1; cp gpurun_out/front_ablation.txt $O/front_ablation.txt
 timeout -k 10 300 python tools/batch_sweep.py 1 $O/batch_sweep_config1.json > /dev/null 2>&1

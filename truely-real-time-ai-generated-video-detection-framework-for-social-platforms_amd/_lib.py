@@ -50,6 +50,7 @@ _SIGNATURES = {
     "trl_debug_level_cands": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "trl_debug_batch_capacity": (C.c_int, [_vp, _f, _f, C.POINTER(_i)]),
     "trl_debug_nms_tiers": (C.c_int, [_vp, _i, _i]),
+    "trl_debug_option": (C.c_int, [_vp, C.c_char_p, _i]),
     "trl_debug_list_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
     "trl_debug_poison": (C.c_int, [_vp, _i]),
     "trl_debug_pyramid_level": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),

@@ -8,6 +8,7 @@
 #include "trl_ctx.h"
 
 static thread_local char g_err[512] = "";
+int g_trl_no_fnconv = 0;
 void trl_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -48,7 +49,7 @@ int trl_create(const trl_config* cfg, trl_ctx** out) {
     c->cfg = *cfg;
     // execution span of every fused PNet launch (two atomics per workgroup, summed on the device: trl_debug_pnet_span);
     // TRL_PNET_CLOCK additionally selects the DBG instantiation with per-phase wave clocks
-    c->pnet_prof = getenv("TRL_PNET_CLOCK") != nullptr;
+    c->pnet_prof = trl_tune_set("TRL_PNET_CLOCK");
     if (hipMalloc((void**)&c->pnet_clk, 8 * 40) != hipSuccess || hipMemset(c->pnet_clk, 0, 8 * 40) != hipSuccess || hipMemset(c->pnet_clk, 0xFF, 8) != hipSuccess ||
         hipMalloc((void**)&c->pnet_cursor, 64) != hipSuccess || hipHostMalloc((void**)&c->h_pinned, 1024) != hipSuccess ||
         hipEventCreate(&c->ev_call0) != hipSuccess || hipEventCreate(&c->ev_call1) != hipSuccess) {
@@ -726,6 +727,18 @@ int trl_debug_list_stats(trl_ctx* c, long long* h_out8) {
     return TRL_OK;
 }
 
+// test hooks of the shipped library (it reads no environment variable): "rnet_chunk" / "onet_chunk" = candidates per R-/O-Net
+// launch set of this context (>= 16), "no_fnconv" = process-wide: FaceNet's small maps through the generic conv kernels
+int trl_debug_option(trl_ctx* c, const char* key, int value) {
+    if (!key) { trl_set_error("null key"); return TRL_ERR_INVALID; }
+    if (!strcmp(key, "no_fnconv")) { g_trl_no_fnconv = value ? 1 : 0; return TRL_OK; }
+    TRL_CHECK(check_idle(c));
+    if (!strcmp(key, "rnet_chunk") && value >= 16) { c->rnet_chunk = value; return TRL_OK; }
+    if (!strcmp(key, "onet_chunk") && value >= 16) { c->onet_chunk = value; return TRL_OK; }
+    trl_set_error("unknown option '%s' (or value %d out of range)", key, value);
+    return TRL_ERR_INVALID;
+}
+
 int trl_debug_batch_capacity(trl_ctx* c, float t2_per_frame, float t3_per_frame, int* last_attempts) {
     if (!c) { trl_set_error("null context"); return TRL_ERR_INVALID; }
     if (t2_per_frame > 0.f) c->t2_per_frame = t2_per_frame;
@@ -753,7 +766,9 @@ int trl_debug_pnet_span(trl_ctx* c, int reset, double* ms_sum, int32_t* launches
     if (!c || !ms_sum || !launches) { trl_set_error("null argument"); return TRL_ERR_INVALID; }
     *ms_sum = 0.0; *launches = 0;
     if (!c->pnet_clk) return TRL_OK;
+    TRL_CHECK(check_idle(c));
     TRL_HIP(hipSetDevice(c->cfg.device));
+    TRL_HIP(hipDeviceSynchronize());                 // the stamps are written by kernels on the callers' streams
     unsigned long long t[2] = {0, 0};
     int khz = 0;
     TRL_HIP(hipMemcpy(t, c->pnet_clk + 36, sizeof t, hipMemcpyDeviceToHost));

@@ -18,13 +18,7 @@
 // R-/O-Net candidates per launch set: one set covers a 256-frame batch's CAPACITY (160 / 48 candidates per frame + 64: 41 k / 12.4 k;
 // 31 k / 8.5 k are live), so no dead second chunk is launched (8 launches x 4.7 us); scratch per chunk = 100 KB / 640 KB per
 // candidate (5 / 10.7 GB at the cap, of 288 GB)
-static int env_chunk(const char* name, int dflt) {
-    const char* e = getenv(name);
-    const int v = e ? atoi(e) : 0;
-    return v >= 16 ? v : dflt;
-}
-// (TRL_RNET_CHUNK / TRL_ONET_CHUNK shrink a launch set for tests, so that the multi-chunk path runs on small inputs)
-static const int TRL_CH2 = env_chunk("TRL_RNET_CHUNK", 49152), TRL_CH3 = env_chunk("TRL_ONET_CHUNK", 16384);
+// (trl_debug_option("rnet_chunk" / "onet_chunk") shrinks a launch set for tests, so that the multi-chunk path runs on small inputs)
 
 namespace {
 
@@ -1173,6 +1167,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         const long long lim = (long long)n * capF;
         c->cap_t2 = (int)(c2 < lim ? c2 : lim);
         c->cap_t3 = (int)(c3 < lim ? c3 : lim);
+        const int TRL_CH2 = c->rnet_chunk, TRL_CH3 = c->onet_chunk;
         const int ch2 = c->cap_t2 < TRL_CH2 ? c->cap_t2 : TRL_CH2, ch3 = c->cap_t3 < TRL_CH3 ? c->cap_t3 : TRL_CH3;
         // per candidate: the front kernel's pooled map + every activation of the tail (trl_run_rnet_tail / trl_run_onet_tail:
         // R-Net 3388 + 3888 + 768 + 576 + 128 floats = 35 KB; O-Net 16928 + 28224 + 6400 + 4096 + 1024 + 1152 + 256 = 227 KB)
@@ -1252,7 +1247,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     X.reset();   // stream order keeps the PNet workspace alive until its kernels are done: reuse needs no host sync
     float* out6 = (float*)X.alloc((size_t)cap2 * 24);
     {
-        const int CH = TRL_CH2;
+        const int CH = c->rnet_chunk;
         const size_t mk = X.off;
         for (int t0 = 0; t0 < cap2; t0 += CH) {
             const int nc = (cap2 - t0 < CH) ? cap2 - t0 : CH;
@@ -1274,7 +1269,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     X.reset();
     float* out16 = (float*)X.alloc((size_t)cap3 * 64);
     {
-        const int CH = TRL_CH3;
+        const int CH = c->onet_chunk;
         const size_t mk = X.off;
         for (int t0 = 0; t0 < cap3; t0 += CH) {
             const int nc = (cap3 - t0 < CH) ? cap3 - t0 : CH;

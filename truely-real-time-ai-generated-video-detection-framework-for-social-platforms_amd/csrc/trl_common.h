@@ -26,6 +26,22 @@ void trl_set_error(const char* fmt, ...);
     } while (0)
 #define TRL_LAUNCH_CHECK() TRL_HIP(hipGetLastError())
 
+// ---- tuning switches ---------------------------------------------------------------------------
+// Experiment / ablation switches (TRL_* environment variables: forced kernel variants, timing-only ablations that produce WRONG
+// detections by construction, tile-size overrides) exist only in a tuning build (`make TUNING=1`); the shipped library reads no
+// environment variable at all.  What the tests need from the shipped library is behind trl_debug_option().
+#ifdef TRL_TUNING
+#include <stdlib.h>
+static inline int trl_tune_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline bool trl_tune_set(const char* name) { return getenv(name) != nullptr; }
+static inline const char* trl_tune_str(const char* name) { return getenv(name); }
+#else
+#define trl_tune_int(name, dflt) (dflt)
+#define trl_tune_set(name) (false)
+#define trl_tune_str(name) ((const char*)nullptr)
+#endif
+extern int g_trl_no_fnconv;   // trl_debug_option("no_fnconv"): test hook, process-wide -- FaceNet's small maps through the generic conv kernels
+
 // ---- device tensors ---------------------------------------------------------------------------
 struct DevW {          // a weight matrix on the device, [Kpad][ld] row-major, zero padded
     float* p = nullptr;

@@ -76,6 +76,7 @@ struct trl_ctx {
     // workspace recent calls needed (with head-room, decaying towards the configured start values)
     float lvl_hint[32] = {0}, frame_hint = 0.f;
     size_t spill_hint = 0;
+    int rnet_chunk = 49152, onet_chunk = 16384;   // R-/O-Net candidates per launch set (trl_cascade.hip; trl_debug_option shrinks them for tests)
     int nms_small = 512, nms_full = 2048;   // LDS tiers of the sort + NMS kernels (candidates); longer lists take the spill tier
                                             // (trl_debug_nms_tiers lowers them so that small test inputs reach every tier)
     int last_attempts = 0;           // attempts the last call took (test hook)

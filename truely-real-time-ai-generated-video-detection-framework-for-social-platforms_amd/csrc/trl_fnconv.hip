@@ -507,7 +507,7 @@ bool trl_fn_split4_rule(const ConvArgs& a) { return fn_split4(a); }
 
 // Does this family take the layer?  Whole-tap chunks of 32 channels, float4-aligned input, 32-bit element offsets, small M.
 bool trl_fn_eligible(const ConvArgs& a) {
-    static const bool off = getenv("TRL_NO_FNCONV") != nullptr;
+    const bool off = g_trl_no_fnconv != 0 || trl_tune_set("TRL_NO_FNCONV");
     if (off || a.lowp || a.m_dev) return false;
     if (a.M <= 0 || a.M > 16384 || a.Cin % 32 != 0 || a.K != a.KH * a.KW * a.Cin) return false;
     if ((a.ldx & 3) || (a.xoff & 3) || (((uintptr_t)a.x) & 15) || (a.ldw & 3)) return false;
@@ -550,13 +550,13 @@ int trl_launch_fn_group(const ConvArgs* convs, int nz, hipStream_t s) {
     // instantiated tiles: single chain {32,64,128}x{32,64,96,128} subset below; four chains {16,32,48}x{32,64}
     Tile t;
     // tuning aid: TRL_FN_FORCE1 / TRL_FN_FORCE4 = "BMxBN" forces the tile of every single-chain / four-chain launch
-    static const char* f1 = getenv("TRL_FN_FORCE1");
-    static const char* f4 = getenv("TRL_FN_FORCE4");
+    static const char* f1 = trl_tune_str("TRL_FN_FORCE1");
+    static const char* f4 = trl_tune_str("TRL_FN_FORCE4");
     const char* force = sp ? f4 : f1;
     int fbm = 0, fbn = 0;
     if (force && sscanf(force, "%dx%d", &fbm, &fbn) == 2) t = Tile{fbm, fbn};
     else t = pick_tile(M, nz == 1 ? convs[0].Cout : N, sp, nz);
-    static const int skip = getenv("TRL_FN_SKIP") ? atoi(getenv("TRL_FN_SKIP")) : 0;
+    static const int skip = trl_tune_int("TRL_FN_SKIP", 0);
     g.skip = skip;
     g.dbg = nullptr;
     if (g_dbg_arm >= 0 && g_dbg_arm-- == 0) g.dbg = g_dbg_buf;

@@ -544,7 +544,7 @@ int slope_mode(const DevV* sl, int n) {
 }  // namespace
 
 // timing-only ablation (TRL_FRONT_SKIP: 1/2 = R-Net crop / conv+pool, 4/8 = O-Net); 0 in production
-static int front_dbg() { static const int v = getenv("TRL_FRONT_SKIP") ? atoi(getenv("TRL_FRONT_SKIP")) : 0; return v; }
+static int front_dbg() { static const int v = trl_tune_int("TRL_FRONT_SKIP", 0); return v; }
 
 // R-Net front: pooled [nc][11][11][28]
 int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, const int32_t* d_total, int t0, int nc,
@@ -554,7 +554,7 @@ int trl_launch_rnet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     const DevV *b = trl_v(c, "rnet.conv1.b"), *sl = trl_v(c, "rnet.prelu1");
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("rnet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->rnet_front_mode < 0) c->rnet_front_mode = slope_mode(sl, 28);
-    static const int rr = getenv("TRL_RNET_R") ? atoi(getenv("TRL_RNET_R")) : 4;     // tuning aid: pooled rows per conv1 strip
+    static const int rr = trl_tune_int("TRL_RNET_R", 4);     // tuning aid: pooled rows per conv1 strip
 #define TRL_RF(RR, MODE, DBG) k_mtcnn_front<24, 28, RR, MODE, DBG><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, reinterpret_cast<const int4*>(c->cb.cbox), \
                                                                        d_total, t0, w->p, b->p, sl->p, d_pool, front_dbg() & 3)
     if (front_dbg() & 3) { if (c->rnet_front_mode == 2) TRL_RF(4, 2, true); else if (c->rnet_front_mode == 1) TRL_RF(4, 1, true); else TRL_RF(4, 0, true); }
@@ -572,7 +572,7 @@ int trl_launch_onet_front(trl_ctx* c, const uint8_t* d_frames, int H, int W, con
     const DevV *b = trl_v(c, "onet.conv1.b"), *sl = trl_v(c, "onet.prelu1");
     if (!w || !b || !sl || w->ld != 32 || w->K != 27) { trl_set_error("onet.conv1 weights"); return TRL_ERR_WEIGHTS; }
     if (c->onet_front_mode < 0) c->onet_front_mode = slope_mode(sl, 32);
-    static const int orr = getenv("TRL_ONET_R") ? atoi(getenv("TRL_ONET_R")) : 1;   // measured: one pooled row per strip = 49 KB of LDS = three resident
+    static const int orr = trl_tune_int("TRL_ONET_R", 1);   // measured: one pooled row per strip = 49 KB of LDS = three resident
                                                                                    // workgroups per CU: 1.18 vs 1.27 ms (R = 3, two per CU) for the O-Net front
 #define TRL_OF(RR, MODE, DBG) k_mtcnn_front<48, 32, RR, MODE, DBG><<<nc, 256, 0, s>>>(d_frames, c->cb.n, H, W, reinterpret_cast<const int4*>(c->cb.cbox), \
                                                                        d_total, t0, w->p, b->p, sl->p, d_pool, (front_dbg() >> 2) & 3)

@@ -730,11 +730,11 @@ template <int BM, int BN, int WM, int WN, int BK>
 int launch_cfg(const ConvArgs& a, bool vec, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN);
     // whole-tap chunks (conv_tap) whenever the channel count allows it and 32-bit element offsets suffice
-    static const bool tap_off = getenv("TRL_NO_TAP") != nullptr;
+    static const bool tap_off = trl_tune_set("TRL_NO_TAP");
     const long long x_elems = (long long)a.N * a.H * a.W * a.ldx + a.xoff;
     if (vec && !tap_off && a.K == a.KH * a.KW * a.Cin && x_elems < 0x7fffffffll && (long long)a.K * a.ldw < 0x7fffffffll) {
         if (BK >= 64 && a.Cin % 64 == 0) return launch_tap<BM, BN, WM, WN, 64>(a, grid, s);
-        static const bool bk16 = getenv("TRL_CONV_BK16") != nullptr;   // tuning aid: 16-channel chunks (half the LDS tile) where 32 divide Cin
+        static const bool bk16 = trl_tune_set("TRL_CONV_BK16");   // tuning aid: 16-channel chunks (half the LDS tile) where 32 divide Cin
         if (a.Cin % 32 == 0 && !bk16) return launch_tap<BM, BN, WM, WN, 32>(a, grid, s);
         if (BM == 128 && BN == 64 && a.Cin % 28 == 0) return launch_tap<BM, BN, WM, WN, 28>(a, grid, s);
         if (a.Cin % 16 == 0) return launch_tap<BM, BN, WM, WN, 16>(a, grid, s);
@@ -917,7 +917,7 @@ int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
     if (a.OH * a.OW <= 9 && a.K >= 512 && (a.K & 15) == 0) {
         if (!vec) { trl_set_error("split-K layer needs Cin %% 4 == 0 and 16-byte aligned input"); return TRL_ERR_INVALID; }
         dim3 grid((a.M + 31) / 32, (a.Cout + 63) / 64);
-        static const bool tap_off = getenv("TRL_NO_TAP") != nullptr;
+        static const bool tap_off = trl_tune_set("TRL_NO_TAP");
         const int segK = a.K >> 2;
         const bool small = (long long)a.N * a.H * a.W * a.ldx + a.xoff < 0x7fffffffll && (long long)a.K * a.ldw < 0x7fffffffll;
         const bool pad = a.ph || a.pw;
@@ -935,7 +935,7 @@ int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
     // the global-load round trip of the next chunk, the only latency hiding a lone workgroup per CU has.
     const bool deep = a.K >= 192;
     {   // Cout == 48 with whole-tap chunks: the 128 x 48 tile (no padded MFMA columns)
-        static const bool tap_off = getenv("TRL_NO_TAP") != nullptr;
+        static const bool tap_off = trl_tune_set("TRL_NO_TAP");
         const bool small = (long long)a.N * a.H * a.W * a.ldx + a.xoff < 0x7fffffffll && (long long)a.K * a.ldw < 0x7fffffffll;
         if (vec && !tap_off && small && a.Cout == 48 && a.ldw >= 48 && a.M >= 16384 && a.K == a.KH * a.KW * a.Cin && (a.Cin % 28 == 0 || a.Cin % 32 == 0)) {
             dim3 grid((a.M + 127) / 128, 1);
@@ -947,7 +947,7 @@ int trl_launch_conv(const ConvArgs& a, hipStream_t s) {
         }
     }
     if (a.Cout <= 32) return deep ? launch_cfg<128, 32, 4, 1, 64>(a, vec, s) : launch_cfg<128, 32, 4, 1, 16>(a, vec, s);
-    static const int bigm = getenv("TRL_CONV_BIGM") ? atoi(getenv("TRL_CONV_BIGM")) : 128;   // tuning aid: row tile of the large-M layers
+    static const int bigm = trl_tune_int("TRL_CONV_BIGM", 128);   // tuning aid: row tile of the large-M layers
     if (a.M >= 16384 && bigm == 128) return deep ? launch_cfg<128, 64, 2, 2, 32>(a, vec, s) : launch_cfg<128, 64, 2, 2, 16>(a, vec, s);
     if (a.M >= 1024) return deep ? launch_cfg<64, 64, 2, 2, 64>(a, vec, s) : launch_cfg<64, 64, 2, 2, 16>(a, vec, s);
     return deep ? launch_cfg<32, 128, 1, 4, 64>(a, vec, s) : launch_cfg<32, 128, 1, 4, 16>(a, vec, s);

@@ -194,7 +194,7 @@ int trl_run_facenet(trl_ctx* c, const float* d_faces, int n, int h, int w, const
     x = R.bconv(x, f + "conv2d_4b", 3, 3, 2, 2, 0, 0);
     if (R.err != TRL_OK) return R.err;
     if (x.h < 3 || x.w < 3) { trl_set_error("face crop %dx%d too small for InceptionResnetV1", h, w); return TRL_ERR_INVALID; }
-    const bool small_f32 = !x.bf && (long long)x.n * x.h * x.w <= 16384 && getenv("TRL_NO_FNCONV") == nullptr;
+    const bool small_f32 = !x.bf && (long long)x.n * x.h * x.w <= 16384 && !(g_trl_no_fnconv != 0 || trl_tune_set("TRL_NO_FNCONV"));
     for (int i = 0; i < 5; i++) x = small_f32 ? block35_grouped(R, x, f + "repeat_1." + std::to_string(i)) : block35(R, x, f + "repeat_1." + std::to_string(i));
     {   // Mixed_6a
         const int OH = (x.h - 3) / 2 + 1, OW = (x.w - 3) / 2 + 1;

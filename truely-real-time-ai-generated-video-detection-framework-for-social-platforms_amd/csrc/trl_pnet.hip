@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every M-tile index below is SALU work
     const int dbg_skip = DBG ? a.dbg_skip : 0;                   // a compile-time 0 in production
-    if (tid == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());   // execution span of the launch (what rocprofv3 calls its duration): two atomics per workgroup, no reply awaited
+    if (DBG && tid == 0) atomicMin(&a.clk[0], (unsigned long long)wall_clock64());   // tuning build: execution span of the launch (first workgroup start .. last workgroup end)
     const int l15 = lane & 15, kq = lane >> 4;      // 16x16x4 operand coordinates
     const int l31 = lane & 31, hh = lane >> 5;      // 32x32x2 operand coordinates
 
@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(256, 2) void k_pnet_fused(PnetArgs a) {
         for (int k = 0; k < 8; k++) atomicAdd(&a.clk[2 + 8 * wave + k], pt[k]);
         if (wave == 0) atomicAdd(&a.clk[2 + 32], (unsigned long long)rot);
     }
-    if (tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
+    if (DBG && tid == 0) atomicMax(&a.clk[1], (unsigned long long)wall_clock64());
 }
 
 }  // namespace
@@ -1424,7 +1424,7 @@ static int fill_args(trl_ctx* c, int n, int H, int W, PnetArgs& a, std::vector<u
     // p = softmax(logit0, logit1)[1] >= thr needs logit1 - logit0 >= ln(thr / (1 - thr)) up to the rounding of the float softmax
     // (~1e-6 relative); 0.05 below that bound the probability is short of thr by 0.05 thr (1 - thr) >= 4.9e-4 for thr in [0.01, 0.99]
     a.dthr = (a.thr >= 0.01f && a.thr <= 0.99f) ? (float)(log((double)a.thr / (1.0 - (double)a.thr)) - 0.05) : -__builtin_inff();
-    { const char* e = getenv("TRL_PNET_SKIP"); a.dbg_skip = e ? atoi(e) : 0; }
+    a.dbg_skip = trl_tune_int("TRL_PNET_SKIP", 0);
     a.lvl_cnt = c->cb.lvl_cnt; a.lvl_rec = c->cb.lvl_rec; a.flags = c->cb.flags;
     a.clk = c->pnet_clk; a.prof = c->pnet_prof ? 1 : 0;
     a.xcd_next = c->pnet_cursor;
@@ -1653,7 +1653,7 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
         int nfine = 0;
         while (nfine < 3 && nfine < a.L && a.lv[nfine].mode == 0 && a.lv[nfine].h <= H && a.lv[nfine].w <= W) nfine++;
         if (nfine >= 2) {
-            static const int strip_env = getenv("TRL_PYR_FINE_STRIP") ? atoi(getenv("TRL_PYR_FINE_STRIP")) : 0;   // tuning: source rows per tile
+            static const int strip_env = trl_tune_int("TRL_PYR_FINE_STRIP", 0);   // tuning: source rows per tile
             const int strip_rows = strip_env >= 8 ? strip_env : 24;
             int band_cols = (int)(62.0 * W / a.lv[0].w);
             std::vector<uint32_t> own;
@@ -1698,17 +1698,17 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
     if (ev) TRL_HIP(hipEventRecord(ev[0], s));
     // Frames are resampled in chunks whose source bytes fit the 256 MiB Infinity Cache: every level re-reads the
     // whole source image, so the 2nd..11th level launches of a chunk are served on-die instead of from HBM.
-    static const int chunk_env = getenv("TRL_PYR_CHUNK") ? atoi(getenv("TRL_PYR_CHUNK")) : 0;
+    static const int chunk_env = trl_tune_int("TRL_PYR_CHUNK", 0);
     int chunk = chunk_env > 0 ? chunk_env : (int)((176ll << 20) / ((long long)H * W * 3));
     if (chunk < 1) chunk = 1;
     if (chunk > n) chunk = n;
     // coarse levels: one streaming pass (k_pyramid_stream) when its preconditions hold, else the per-level kernels
     // Streaming pass (k_pyramid_stream) for the coarse levels (mode != 0); optionally (TRL_PYR_STREAM_FINE=1) a second one for
     // the fine levels.  A group that does not meet the kernel's preconditions falls back to the per-level kernels below.
-    static const bool stream_off = getenv("TRL_PYR_STREAM") && atoi(getenv("TRL_PYR_STREAM")) == 0;
-    static const bool fine_on = getenv("TRL_PYR_STREAM_FINE") && atoi(getenv("TRL_PYR_STREAM_FINE")) != 0;   // measured: 1.75 vs 1.83 ms, not worth a default
-    static const int bands_env = getenv("TRL_PYR_BANDS") ? atoi(getenv("TRL_PYR_BANDS")) : 0;
-    static const int fbands_env = getenv("TRL_PYR_FINE_BANDS") ? atoi(getenv("TRL_PYR_FINE_BANDS")) : 0;
+    static const bool stream_off = trl_tune_int("TRL_PYR_STREAM", 1) == 0;
+    static const bool fine_on = trl_tune_int("TRL_PYR_STREAM_FINE", 0) != 0;   // measured: 1.75 vs 1.83 ms, not worth a default
+    static const int bands_env = trl_tune_int("TRL_PYR_BANDS", 0);
+    static const int fbands_env = trl_tune_int("TRL_PYR_FINE_BANDS", 0);
     bool streamed[16] = {};
     auto stream_group = [&](bool fine, int row_bands) -> int {
         PyrStreamArgs sa;
@@ -1729,7 +1729,7 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
         if (sa.nlev == 0 || stab_words > STAB || n > 65535) return TRL_OK;
         // Frames wider than one 4096-byte column band need several bands per row; measured at 1080p and 4K the pass then
         // gains nothing over the per-level kernels and the PNet launch that follows runs 7-10 % slower: keep it to one band.
-        static const bool wide_env = getenv("TRL_PYR_STREAM_WIDE") && atoi(getenv("TRL_PYR_STREAM_WIDE")) != 0;
+        static const bool wide_env = trl_tune_int("TRL_PYR_STREAM_WIDE", 0) != 0;
         if (W * 3 > SBYTES && !wide_env) return TRL_OK;
         sa.H = H; sa.W = W; sa.n_frames = n; sa.pyr_stride = a.pyr_stride;
         if (W * 3 <= SBYTES) { sa.col_bands = 1; sa.cols_per_band = W; }
@@ -1751,7 +1751,7 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
     }
     const bool stream_ok = true;
     // the finest levels in one pass over the source (TRL_PYR_FINE=0: the per-level kernels)
-    static const bool fine_off = getenv("TRL_PYR_FINE") && atoi(getenv("TRL_PYR_FINE")) == 0;
+    static const bool fine_off = trl_tune_int("TRL_PYR_FINE", 1) == 0;
     if (!fine_off && c->pyr_fine.nlev >= 2 && n <= 65535 && c->pyr_fine.n_strips <= 65535) {
         PyrFineArgs fa;
         fa.H = H; fa.W = W; fa.n_frames = n; fa.f0 = 0; fa.pyr_stride = a.pyr_stride;
@@ -1806,19 +1806,23 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     PnetArgs a;
     TRL_CHECK(build_pyramid(c, d_frames, n, H, W, a, ev, s));
     const int total_tiles = a.tiles_per_frame * n;
-    static const int grid_env = getenv("TRL_PNET_GRID") ? atoi(getenv("TRL_PNET_GRID")) : 0;   // experiment: workgroups of the persistent launch
+    static const int grid_env = trl_tune_int("TRL_PNET_GRID", 0);   // experiment: workgroups of the persistent launch
     int grid = grid_env > 0 ? grid_env : 256 * 2;   // 2 resident workgroups per CU (<= 256 VGPRs)
     if (grid > ((total_tiles + 7) / 8) * 8) grid = ((total_tiles + 7) / 8) * 8;
     if (grid < 8) grid = 8;
     TRL_HIP(hipMemsetAsync(c->pnet_cursor, 0, 8 * sizeof(int32_t), s));
     if (ev) TRL_HIP(hipEventRecord(ev[2], s));   // the event pair brackets the kernel alone (HIP events on the launch's stream)
-    static const int xlds = getenv("TRL_PNET_XLDS") ? atoi(getenv("TRL_PNET_XLDS")) : 0;   // experiment: unused dynamic LDS, lowers the resident workgroups per CU
+    static const int xlds = trl_tune_int("TRL_PNET_XLDS", 0);   // experiment: unused dynamic LDS, lowers the resident workgroups per CU
     // instantiation: slopes all <= 1 or not, a negative conv1 slope or not, diagnostics (TRL_PNET_CLOCK / TRL_PNET_SKIP) or not
-    const bool dbg = c->pnet_prof || a.dbg_skip;
+#ifdef TRL_TUNING
+    const bool dbg = c->pnet_prof || a.dbg_skip || trl_tune_set("TRL_PNET_SPAN");   // the instantiation with clock stamps / ablations
+#else
+    const bool dbg = false;                              // (not even instantiated in the shipped library)
+#endif
     // Tiles per cursor fetch: a run of 24 = 8 columns of a 3-row band (7 of 8 columns carry horizontally, 2 of 3 rows vertically);
     // small batches keep shorter runs, down to single tiles, so that every CU gets work
     // (TRL_PNET_RUN / trl_debug_pnet_run override: tuning, and tests that exercise the carry path on small frames)
-    static const int run_env = getenv("TRL_PNET_RUN") ? atoi(getenv("TRL_PNET_RUN")) : 0;
+    static const int run_env = trl_tune_int("TRL_PNET_RUN", 0);
     const int auto_run = (total_tiles / 8) / 128;
     a.run = c->pnet_run > 0 ? c->pnet_run : (run_env > 0 ? run_env : (auto_run < 1 ? 1 : (auto_run > 8 * BAND ? 8 * BAND : auto_run)));
     auto launch = [&](auto kern) {
@@ -1828,14 +1832,20 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         return true;
     };
     bool launched = false;
+#ifdef TRL_TUNING
 #define TRL_PK(U, N) do { launched = dbg ? launch(k_pnet_fused<U, N, true>) : launch(k_pnet_fused<U, N, false>); } while (0)
+#else
+#define TRL_PK(U, N) do { launched = launch(k_pnet_fused<U, N, false>); } while (0)
+#endif
     if (c->pnet_unit) { if (c->pnet_mono1) TRL_PK(true, false); else TRL_PK(true, true); }
     else { if (c->pnet_mono1) TRL_PK(false, false); else TRL_PK(false, true); }
 #undef TRL_PK
     if (!launched) { trl_set_error("k_pnet_fused: %d bytes of dynamic LDS refused", DYN_LDS + xlds); return TRL_ERR_HIP; }
     TRL_LAUNCH_CHECK();
     if (ev) TRL_HIP(hipEventRecord(ev[3], s));
-    k_pnet_span<<<1, 1, 0, s>>>(c->pnet_clk);   // fold the launch's span into the running sums, re-arm the two stamps
-    TRL_LAUNCH_CHECK();
+    if (dbg) {
+        k_pnet_span<<<1, 1, 0, s>>>(c->pnet_clk);   // fold the launch's span into the running sums, re-arm the two stamps
+        TRL_LAUNCH_CHECK();
+    }
     return TRL_OK;
 }

@@ -274,6 +274,10 @@ class Engine:
         _lib.check(self.lib.trl_debug_batch_capacity(self._h, float(t2_per_frame), float(t3_per_frame), C.byref(k)))
         return k.value
 
+    def option(self, key: str, value: int):
+        """Test hook (``trl_debug_option``): "rnet_chunk" / "onet_chunk" (this context), "no_fnconv" (process-wide)."""
+        _lib.check(self.lib.trl_debug_option(self._h, key.encode(), int(value)))
+
     def nms_tiers(self, small: int = 0, full: int = 0):
         """Test hook: LDS tiers (candidates per list) of the sort + NMS kernels; lists longer than ``full`` take the
         global-memory spill tier.  Results never depend on the tiers."""
