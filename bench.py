@@ -200,21 +200,37 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def rank_command(args, argv, have_gpus, environ=None):
+    """(cmd, env) of the child launcher that `--gpus N` without a launcher starts: N fresh ranks under torch.distributed.run on
+    this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve), dmabuf IPC for RCCL."""
+    if args.backend == "nccl" and have_gpus < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} with RCCL needs {args.gpus} visible GPUs, found {have_gpus} "
+                         f"(rehearse on fewer GPUs with --backend gloo)")
+    port = args.master_port or (29500 + os.getpid() % 3000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ if environ is None else environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    return cmd, env
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: start N fresh ranks as a child `torch.distributed.run` (never re-exec: this
     process has not touched the GPU and never will).  torch.cuda.device_count() does not initialise HIP."""
     import torch
-    have = torch.cuda.device_count()
-    if args.backend == "nccl" and have < args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} with RCCL needs {args.gpus} visible GPUs, found {have} "
-                 f"(rehearse on fewer GPUs with --backend gloo)")
-    port = args.master_port or (29500 + os.getpid() % 3000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "2")
+    cmd, env = rank_command(args, sys.argv[1:], torch.cuda.device_count())
     return subprocess.call(cmd, env=env)
+
+
+def rank_device(local_rank, world, backend, device_count):
+    """The device ordinal of a rank.  RCCL: one GPU per rank, LOCAL_RANK is the ordinal (a node with fewer GPUs than ranks is an
+    error, not a silent share).  gloo rehearsals may stack several ranks on one GPU."""
+    if backend != "nccl":
+        return local_rank % max(1, device_count)
+    if world > device_count:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, found {device_count}")
+    return local_rank
 
 
 def main():
@@ -232,18 +248,15 @@ def main():
     import torch.distributed as dist
     import truely_amd
     from truely_amd.engine import Engine
-    from truely_amd.distributed import allgather_embeddings
+    from truely_amd.distributed import allgather_embeddings_async
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
-    if args.backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share one GPU under gloo
-    elif world > torch.cuda.device_count():
-        sys.exit(f"bench.py: {world} RCCL ranks need {world} GPUs, found {torch.cuda.device_count()}")
-    torch.cuda.set_device(local)
+    local = rank_device(local, world, args.backend, torch.cuda.device_count())   # (device_count() does not initialise HIP)
+    torch.cuda.set_device(local)                              # before ANY HIP call of this rank: contexts, RCCL, tensors
     dev = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
     if args.force_dist and world == 1:
@@ -302,20 +315,45 @@ def main():
 
     counts = [n] * world
 
-    def finish(out):
-        """Main thread, step order on every rank: the one collective of the path (sharded mode), then the drift state machine."""
+    def gather_start(out):
+        """Main thread, step order on every rank: START the one collective of the path (sharded mode) for this step's rows.  It is
+        consumed one step later (gather_finish), so a rank that is momentarily slower does not stall the others inside every step:
+        the collective (8 x 0.53 MB, latency-bound) is off the critical path."""
         if use_dist and sharded:
-            emb, valid = allgather_embeddings(out["emb"], out["valid"], counts=counts)
-        else:
-            emb, valid = out["emb"], out["valid"]
+            return allgather_embeddings_async(out["emb"], out["valid"], counts=counts)
+        return (out["emb"], out["valid"])
+
+    def gather_finish(h):
+        """... and consume it: the time-ordered rows of the whole clip, then the drift state machine (every rank)."""
+        emb, valid = h.wait() if hasattr(h, "wait") else h
         d = drift_eng.drift_score(emb, valid, frame_count, FPS)
         d["emb_all"], d["valid_all"] = emb, valid
         return d
 
+    class Lagged:
+        """finish() of the steps: the gather of step i is started when its rows exist and finished when step i + 1's rows exist
+        (or at drain()): results stay in step order, all of it inside the timed region."""
+
+        def __init__(self):
+            self.prev = None            # (out, gather handle) of the previous step
+            self.last = (None, None)
+
+        def step(self, out):
+            h = gather_start(out)
+            if self.prev is not None:
+                self.last = (self.prev[0], gather_finish(self.prev[1]))
+            self.prev = (out, h)
+
+        def drain(self):
+            if self.prev is not None:
+                self.last = (self.prev[0], gather_finish(self.prev[1]))
+                self.prev = None
+            return self.last
+
     def run_steps(k):
         """k steps.  Worker j runs detect+embed of steps j, j+F, .. on its own stream; results are consumed in step order."""
         acc = {"pnet_ms": 0.0, "pyramid_ms": 0.0, "pnet_kernel_ms": 0.0}
-        last = (None, None)
+        lag = Lagged()
         G = max(1, args.embed_group)
 
         def group(engine, j, idxs):
@@ -338,11 +376,10 @@ def main():
         if F == 1 and args.driver == "threads":
             for g0 in range(0, k, G):
                 for out, tm in group(eng, 0, list(range(g0, min(k, g0 + G)))):
-                    d = finish(out)
+                    lag.step(out)
                     for key in acc:
                         acc[key] += tm[key]
-                    last = (out, d)
-            return last, acc
+            return lag.drain(), acc
         if args.driver == "single":
             # ONE host thread over all contexts (pipeline.detect_embed_overlapped): step i is queued on context i % F
             # (trl_detect_embed_begin returns without synchronising) and finished right before that context is needed again; with
@@ -356,12 +393,11 @@ def main():
                     acc[key] += tm[key]
 
             def on_result(i, out):
-                nonlocal last
-                last = (out, finish(out))
+                lag.step(out)
 
             detect_embed_overlapped(engs, lambda i, j: batch_input(j, i + F < k), on_result=on_result, streams=streams,
                                     embed_group=G, embed_engine=embed_eng, n_batches=k, on_detect=on_detect)
-            return last, acc
+            return lag.drain(), acc
         qs = [queue.Queue() for _ in range(F)]
 
         def worker(j):
@@ -385,13 +421,12 @@ def main():
             if isinstance(item, BaseException):
                 raise item
             out, tm = item
-            d = finish(out)
+            lag.step(out)
             for key in acc:
                 acc[key] += tm[key]
-            last = (out, d)
         for t in ths:
             t.join()
-        return last, acc
+        return lag.drain(), acc
 
     def fence():
         if use_dist:

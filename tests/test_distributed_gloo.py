@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import truely_amd  # noqa: F401
-    from truely_amd.distributed import allgather_embeddings, shard_bounds, shard_counts
+    from truely_amd.distributed import allgather_embeddings, allgather_embeddings_async, shard_bounds, shard_counts
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(42)
@@ -36,6 +36,11 @@ def _worker(rank, world, port, q):
         ok = False
     except ValueError:
         pass
+    # two gathers in flight, consumed one step late (what bench.py's step loop does): same rows, in order
+    h1 = allgather_embeddings_async(torch.from_numpy(emb[lo:hi]), torch.from_numpy(valid[lo:hi]), counts=shard_counts(n, world))
+    h2 = allgather_embeddings_async(torch.from_numpy(emb[lo:hi] * 2), torch.from_numpy(valid[lo:hi]), counts=shard_counts(n, world))
+    (ea, va), (eb, vb) = h1.wait(), h2.wait()
+    ok = ok and np.array_equal(ea.numpy(), emb) and np.array_equal(eb.numpy(), emb * 2) and np.array_equal(vb.numpy(), valid)
     # empty shard on one rank
     e2, v2 = allgather_embeddings(torch.from_numpy(emb[:3] if rank == 0 else emb[:0]), torch.from_numpy(valid[:3] if rank == 0 else valid[:0]))
     ok = ok and e2.shape == (3, 512) and np.array_equal(v2.numpy(), valid[:3])

@@ -127,6 +127,34 @@ def test_bench_flop_model_matches_survey():
     assert abs(bench.pnet_macs(360, 640) / 1e6 - 281.2) < 0.1
 
 
+def test_bench_multi_gpu_launch_is_correct_by_construction():
+    """The 8-GPU run is the driver's to launch (no node here): what can be checked without hardware.  `--gpus 8` without a
+    launcher starts torch.distributed.run with 8 ranks on this node, rendezvous on 127.0.0.1, dmabuf IPC for RCCL, and passes the
+    bench flags through; each rank takes LOCAL_RANK as its device -- set before ANY HIP call (engines, process group, tensors) --
+    and RCCL refuses to stack ranks on fewer GPUs, while gloo rehearsals may."""
+    import bench
+    args = bench.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    cmd, env = bench.rank_command(args, ["--gpus", "8", "--steps", "20", "--warmup", "5"], have_gpus=8, environ={"PATH": "/usr/bin"})
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 1024
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/usr/bin"
+    with pytest.raises(SystemExit):
+        bench.rank_command(args, [], have_gpus=1)                        # RCCL needs one GPU per rank
+    assert [bench.rank_device(r, 8, "nccl", 8) for r in range(8)] == list(range(8))
+    with pytest.raises(SystemExit):
+        bench.rank_device(3, 8, "nccl", 4)
+    assert [bench.rank_device(r, 4, "gloo", 1) for r in range(4)] == [0, 0, 0, 0]
+    # set_device(LOCAL_RANK) comes before anything that initialises HIP in a rank
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def main():"):]
+    at = body.index("torch.cuda.set_device(local)")
+    for later in ("init_process_group(", "Engine(blob", ".to(dev)", "torch.cuda.Stream(", "pin_memory()"):
+        assert at < body.index(later), later
+    assert body.index("spawn_ranks(args)") < body.index("import torch")  # the parent never touches the GPU
+
+
 def test_analysis_service_keeps_event_loop_free():
     """requests queue on one worker, in order, while the event loop keeps running."""
     import asyncio

@@ -31,15 +31,34 @@ def shard_counts(n: int, world: int):
     return [shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)]
 
 
-def allgather_embeddings(emb: torch.Tensor, valid: torch.Tensor, counts: Optional[Sequence[int]] = None, group=None,
-                         box: Optional[torch.Tensor] = None, rect: Optional[torch.Tensor] = None):
-    """All-gather per-rank shards of result rows and return them time-ordered.
+class GatherHandle:
+    """An all-gather of result rows in flight (``allgather_embeddings_async``).  ``wait()`` returns the time-ordered rows; with RCCL
+    it makes the CURRENT STREAM wait for the collective (the host does not block), with gloo it blocks the host."""
 
-    ``counts`` = the shard size of every rank when the caller knows it (``shard_counts``: contiguous shards of a
-    clip of known length): the gather is then ONE collective and no host synchronisation.  Without it the sizes
-    are exchanged first (one small all-gather + a host read).  Shards may be ragged or empty; they travel padded
-    to the largest shard.  Returns ``(emb, valid)`` or, when ``box``/``rect`` are given, ``(emb, valid, box, rect)``.
-    """
+    def __init__(self, work, out, sizes, m, extra):
+        self.work, self.out, self.sizes, self.m, self.extra = work, out, sizes, m, extra
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        out, sizes, m = self.out, self.sizes, self.m
+        if all(s == m for s in sizes):
+            rows = out
+        else:
+            out = out.view(len(sizes), m, _ROW)
+            rows = torch.cat([out[r, :sizes[r]] for r in range(len(sizes))])
+        e, v = rows[:, :512].contiguous(), rows[:, 512].to(torch.uint8).contiguous()
+        if not self.extra:
+            return e, v
+        return e, v, rows[:, 513:517].contiguous(), rows[:, 517:521].contiguous().view(torch.int32)
+
+
+def allgather_embeddings_async(emb: torch.Tensor, valid: torch.Tensor, counts: Optional[Sequence[int]] = None, group=None,
+                               box: Optional[torch.Tensor] = None, rect: Optional[torch.Tensor] = None) -> GatherHandle:
+    """Start the all-gather of per-rank shards of result rows and return at once (``async_op=True``): a caller that consumes the
+    rows one step later never stalls on a slower rank inside a step -- the per-step collective leaves the critical path
+    (bench.py).  See :func:`allgather_embeddings` for the arguments."""
     world = dist.get_world_size(group)
     n_loc = int(emb.shape[0])
     if counts is None:
@@ -61,16 +80,20 @@ def allgather_embeddings(emb: torch.Tensor, valid: torch.Tensor, counts: Optiona
     if rect is not None:
         pay[:n_loc, 517:521] = rect.to(torch.int32).contiguous().view(torch.float32)
     out = torch.empty((world * m, _ROW), dtype=torch.float32, device=emb.device)
-    dist.all_gather_into_tensor(out, pay, group=group)
-    if all(s == m for s in sizes):
-        rows = out
-    else:
-        out = out.view(world, m, _ROW)
-        rows = torch.cat([out[r, :sizes[r]] for r in range(world)])
-    e, v = rows[:, :512].contiguous(), rows[:, 512].to(torch.uint8).contiguous()
-    if box is None and rect is None:
-        return e, v
-    return e, v, rows[:, 513:517].contiguous(), rows[:, 517:521].contiguous().view(torch.int32)
+    work = dist.all_gather_into_tensor(out, pay, group=group, async_op=True)
+    return GatherHandle(work, out, sizes, m, box is not None or rect is not None)
+
+
+def allgather_embeddings(emb: torch.Tensor, valid: torch.Tensor, counts: Optional[Sequence[int]] = None, group=None,
+                         box: Optional[torch.Tensor] = None, rect: Optional[torch.Tensor] = None):
+    """All-gather per-rank shards of result rows and return them time-ordered.
+
+    ``counts`` = the shard size of every rank when the caller knows it (``shard_counts``: contiguous shards of a
+    clip of known length): the gather is then ONE collective and no host synchronisation.  Without it the sizes
+    are exchanged first (one small all-gather + a host read).  Shards may be ragged or empty; they travel padded
+    to the largest shard.  Returns ``(emb, valid)`` or, when ``box``/``rect`` are given, ``(emb, valid, box, rect)``.
+    """
+    return allgather_embeddings_async(emb, valid, counts=counts, group=group, box=box, rect=rect).wait()
 
 
 def analyze_video_sharded(frames_local, fps: int, frame_count: int, engine: Engine | None = None, group=None,
