@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds profiles/<tag>_* from gpurun_out/refresh/ (written by tools/refresh_profiles.sh on the GPU box).
 
-  python tools/collect_profiles.py [tag]        # tag defaults to round3
+  python tools/collect_profiles.py [tag]        # tag defaults to round4
 """
 import csv
 import json
@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "round3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "round4"
 
 
 def pmc_rows(path, counter):
@@ -34,19 +34,21 @@ def pmc_rows(path, counter):
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench.json"))
-    shutil.copy(os.path.join(SRC, "stats2", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats.csv"))            # default command
-    shutil.copy(os.path.join(SRC, "stats", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats_inflight1.csv"))   # --in-flight 1
-    shutil.copy(os.path.join(SRC, "bench_inflight1.json"), os.path.join(DST, f"{tag}_bench_inflight1.json"))
+    shutil.copy(os.path.join(SRC, "stats", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats.csv"))             # the driver's command (one batch in flight)
+    if os.path.exists(os.path.join(SRC, "stats2", "s_kernel_stats.csv")):
+        shutil.copy(os.path.join(SRC, "stats2", "s_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats_inflight2.csv"))  # --in-flight 2
+    if os.path.exists(os.path.join(SRC, "bench_inflight2.json")):
+        shutil.copy(os.path.join(SRC, "bench_inflight2.json"), os.path.join(DST, f"{tag}_bench_inflight2.json"))
     summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), os.path.join(SRC, "stats", "s_kernel_trace.csv"), "2", "--all"],
                           capture_output=True, text=True, check=True).stdout
-    open(os.path.join(DST, f"{tag}_step_timeline_inflight1.txt"), "w").write(summ)
+    open(os.path.join(DST, f"{tag}_step_timeline.txt"), "w").write(summ)
     for name in ("bench_sustained", "bench_config2", "bench_config4", "bench_prelu_general", "bench_prelu_general_inflight1", "bench_ingest_nv12",
                  "bench_gloo2_sharded", "bench_gloo2_streams", "bench_gloo2_streams_nv12", "bench_embed_group3", "bench_config0", "run_config0",
                  "bench_driver_threads", "bench_embed_group1", "bench_embed_group4", "bench_inflight1_group1", "bench_inflight1_group1_nocarry"):
         src = os.path.join(SRC, name + ".json")
         if os.path.exists(src) and os.path.getsize(src) > 0:
             shutil.copy(src, os.path.join(DST, f"{tag}_{name}.json"))
-    for sub, out in (("stats_c2", "config2_kernel_stats_inflight1.csv"), ("stats_c4", "config4_kernel_stats_inflight1.csv"),
+    for sub, out in (("stats_c2", "config2_kernel_stats.csv"), ("stats_c4", "config4_kernel_stats.csv"),
                      ("stats_fn2048", "facenet_2048faces_kernel_stats.csv")):
         src = os.path.join(SRC, sub, "s_kernel_stats.csv")
         if os.path.exists(src):
@@ -84,7 +86,7 @@ def main():
     hbm = (2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024.0
     traffic = {
         "kernel": "k_pnet_fused",
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 --no-cpu-baseline --in-flight 1",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
         "FETCH_SIZE_KB_per_launch": per_launch["FETCH_SIZE"],
         "WRITE_SIZE_KB_per_launch": per_launch["WRITE_SIZE"],
         "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced 16 B/lane reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact",

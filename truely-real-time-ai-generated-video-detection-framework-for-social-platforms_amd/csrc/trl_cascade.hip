@@ -1309,10 +1309,15 @@ int trl_cascade_check(trl_ctx* c, int n, int* retry) {
     unsigned long long spill_used = 0;
     memcpy(&spill_used, f + FLG_SPILL_CUR, 8);
     if (f[FLG_LEVEL]) {                                  // every later stage ran on truncated lists: their totals mean nothing
+        long long sum = 0;
         for (int l = 0; l < L; l++) {
             const float want = 1.25f * (float)f[FLG_LEVEL_MAX + l] + 4.f;
             if (f[FLG_LEVEL_MAX + l] > c->cb.lay.capl[l] && want > c->lvl_hint[l]) c->lvl_hint[l] = want;
+            sum += f[FLG_LEVEL_MAX + l];
         }
+        // a frame's stage-1 list is a subset of its candidates: when the per-frame lists of the batch stay under 8 GB at that bound,
+        // grow them in the same step (one attempt less for crowded content; otherwise the next attempt measures the real total)
+        if ((float)sum > c->frame_hint && (double)sum * 132.0 * (double)n < 8e9) c->frame_hint = (float)sum;
         *retry = 1;
         return TRL_OK;
     }
