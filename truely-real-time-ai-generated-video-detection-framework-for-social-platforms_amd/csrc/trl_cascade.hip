@@ -255,14 +255,34 @@ __device__ void big_bitonic(uint64_t* gk, uint32_t* gi, int P, uint64_t* lk, uin
 }
 // Greedy NMS of the first m entries of the sorted list (payload gi -> box through box_of).  kbox / karea / kid (global, m entries)
 // receive the kept boxes, their areas and payloads in pick order.  S: LDS carve with room for C entries.  Returns the kept count.
+//
+// A chunk is first tested against the boxes kept from earlier chunks.  IoU mode (grid != null): through a uniform grid over the
+// kept boxes' CENTRES (32-px cells, linked lists in global memory: head[cell], next[kept]).  A kept box i can only suppress a
+// candidate j if they intersect AND inter > thr * area_i, hence w_i < w_j / thr and h_i < h_j / thr, hence
+// |cx_i - cx_j| < w_j (1 + 1/thr) / 2 (same in y): the candidate walks the cells of that window only -- the pairs it skips could
+// not have suppressed it, the pairs it tests are tested exactly as before, so every decision is the brute-force one.  Cell
+// indices are clamped to the grid on both sides (boxes regressed past the frame land in the border cells).  'Min' mode has no such
+// bound (a box of any size suppresses the boxes inside it): it tests against every kept box, staged through LDS in tiles.
+struct KeptGrid { int* head; int* next; int gx, gy; };
+constexpr int GRID_SHIFT = 5;
+__device__ __forceinline__ int grid_clamp(float v, int n) {
+    int c = (int)floorf(v * (1.0f / (1 << GRID_SHIFT)));
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
 template <bool MIN_MODE, class BoxOf>
 __device__ int big_greedy(const Smem& S, int C, const uint32_t* gi, int m, float thr, BoxOf box_of, float4* kbox, float* karea,
-                          uint32_t* kid) {
-    // kept boxes of earlier chunks are staged through LDS in tiles (the key area is idle during NMS: 8 C bytes = TK boxes + areas)
+                          uint32_t* kid, KeptGrid grid) {
+    // 'Min' mode: kept boxes of earlier chunks are staged through LDS in tiles (the key area is idle during NMS: 8 C bytes = TK boxes + areas)
     const int TK = (C * 8) / 20;
     float4* tb = (float4*)S.key;
     float* ta = (float*)(tb + TK);
     constexpr int E = 2;                                  // entries of a chunk per thread: the spill tier runs with 1024 threads (C <= 2048)
+    const bool use_grid = !MIN_MODE && grid.head != nullptr;
+    if (use_grid) {
+        for (int t = threadIdx.x; t < grid.gx * grid.gy; t += blockDim.x) grid.head[t] = -1;
+        __syncthreads();
+    }
+    const float reach = 0.5f * (1.0f + 1.0f / thr);       // window half-size in units of the candidate's own extent (+ 1 px below)
     int K = 0;
     for (int base = 0; base < m; base += C) {
         const int nc = m - base < C ? m - base : C;
@@ -280,19 +300,40 @@ __device__ int big_greedy(const Smem& S, int C, const uint32_t* gi, int m, float
                 sp[e] = false;
             }
         }
-        // boxes kept from earlier chunks: every thread tests its own entries of the chunk against a tile of them at a time
-        for (int k0 = 0; k0 < K; k0 += TK) {
-            const int nt = K - k0 < TK ? K - k0 : TK;
-            __syncthreads();
-            for (int i = threadIdx.x; i < nt; i += blockDim.x) { tb[i] = kbox[k0 + i]; ta[i] = karea[k0 + i]; }
-            __syncthreads();
+        if (use_grid) {
+            if (K > 0) {
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                if (sp[e]) continue;
-                bool s = false;
+                for (int e = 0; e < E; e++) {
+                    if (sp[e]) continue;
+                    const float4 b = bt[e];
+                    const float w = b.z - b.x, h = b.w - b.y;
+                    if (!(w > 0.f) || !(h > 0.f)) continue;                   // an empty box intersects nothing: never suppressed
+                    const float cx = 0.5f * (b.x + b.z), cy = 0.5f * (b.y + b.w), rx = w * reach + 1.f, ry = h * reach + 1.f;
+                    const int x0 = grid_clamp(cx - rx, grid.gx), x1 = grid_clamp(cx + rx, grid.gx);
+                    const int y0 = grid_clamp(cy - ry, grid.gy), y1 = grid_clamp(cy + ry, grid.gy);
+                    bool s = false;
+                    for (int gy = y0; gy <= y1 && !s; gy++)
+                        for (int gx = x0; gx <= x1 && !s; gx++)
+                            for (int k = __hip_atomic_load(&grid.head[gy * grid.gx + gx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); k >= 0 && !s; k = grid.next[k])   // (head is updated by atomics at L2: read it there)
+                                s = nms_suppresses<false>(kbox[k], karea[k], b, at[e], thr);
+                    sp[e] = s;
+                }
+            }
+        } else {
+            // boxes kept from earlier chunks: every thread tests its own entries of the chunk against a tile of them at a time
+            for (int k0 = 0; k0 < K; k0 += TK) {
+                const int nt = K - k0 < TK ? K - k0 : TK;
+                __syncthreads();
+                for (int i = threadIdx.x; i < nt; i += blockDim.x) { tb[i] = kbox[k0 + i]; ta[i] = karea[k0 + i]; }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if (sp[e]) continue;
+                    bool s = false;
 #pragma unroll 4
-                for (int k = 0; k < nt; k++) s |= nms_suppresses<MIN_MODE>(tb[k], ta[k], bt[e], at[e], thr);
-                sp[e] = s;
+                    for (int k = 0; k < nt; k++) s |= nms_suppresses<MIN_MODE>(tb[k], ta[k], bt[e], at[e], thr);
+                    sp[e] = s;
+                }
             }
         }
 #pragma unroll
@@ -304,7 +345,12 @@ __device__ int big_greedy(const Smem& S, int C, const uint32_t* gi, int m, float
         const int nk = block_nms<MIN_MODE>(S.box, S.area, nc, thr, S.sup, S.keep, S.scal, true);
         for (int r = threadIdx.x; r < nk; r += blockDim.x) {
             const int t = S.keep[r];
-            kbox[K + r] = S.box[t]; karea[K + r] = S.area[t]; kid[K + r] = S.id[t];
+            const float4 b = S.box[t];
+            kbox[K + r] = b; karea[K + r] = S.area[t]; kid[K + r] = S.id[t];
+            if (use_grid) {                               // register the kept box under its centre's cell
+                const int cell = grid_clamp(0.5f * (b.y + b.w), grid.gy) * grid.gx + grid_clamp(0.5f * (b.x + b.z), grid.gx);
+                grid.next[K + r] = atomicExch(&grid.head[cell], K + r);
+            }
         }
         K += nk;
         __syncthreads();
@@ -394,7 +440,7 @@ __global__ void k_heads_to_maps(const float* __restrict__ heads, int cells, floa
 // (LDS for 2048 candidates: 94 KB, one workgroup per CU) the crowded ones, through LDS up to its capacity and through the spill
 // tier (global memory) beyond; a workgroup whose segment belongs to the other tier exits at once.  One tier for everything ran
 // the 2,816 segments of a 256-frame batch in eleven rounds of 256.
-__global__ __launch_bounds__(1024) void k_nms_level(LvLayout G, int lds_cap, int min_cnt, int spill_tier, const int32_t* __restrict__ lvl_cnt,
+__global__ __launch_bounds__(1024) void k_nms_level(LvLayout G, int lds_cap, int min_cnt, int spill_tier, int W, int H, const int32_t* __restrict__ lvl_cnt,
                                                    const Cand* __restrict__ lvl_rec,
                                                    int32_t* __restrict__ keep_cnt, int32_t* __restrict__ keep_idx,
                                                    int32_t* __restrict__ flags, Spill sp) {
@@ -413,10 +459,12 @@ __global__ __launch_bounds__(1024) void k_nms_level(LvLayout G, int lds_cap, int
     int32_t* kout = keep_idx + (size_t)f * G.S + G.rec0[l];
     if (cnt > lds_cap) {                                                          // ---- spill tier
         const int P = next_pow2(cnt);
-        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)cnt * 20);
+        const int gx = (W >> GRID_SHIFT) + 1, gy = (H >> GRID_SHIFT) + 1;
+        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)cnt * 24 + (size_t)gx * gy * 4);
         if (!w) { if (threadIdx.x == 0) keep_cnt[seg] = 0; return; }
         uint64_t* gk = (uint64_t*)w; uint32_t* gi = (uint32_t*)(gk + P);
         float4* kbox = (float4*)(gi + P); float* karea = (float*)(kbox + cnt);
+        const KeptGrid grid{(int*)(karea + cnt) + cnt, (int*)(karea + cnt), gx, gy};
         for (int t = threadIdx.x; t < P; t += blockDim.x) {
             gk[t] = t < cnt ? (((uint64_t)(~f2ord(recs[t].score))) << 32) | (uint32_t)recs[t].cell : ~0ull;
             gi[t] = t;
@@ -425,7 +473,7 @@ __global__ __launch_bounds__(1024) void k_nms_level(LvLayout G, int lds_cap, int
         big_bitonic(gk, gi, P, S.key, S.id, pow2_floor(lds_cap));
         const int nk = big_greedy<false>(S, pow2_floor(lds_cap), gi, cnt, 0.5f,
                                          [&](uint32_t id) { const Cand& c = recs[id]; return make_float4(c.x1, c.y1, c.x2, c.y2); },
-                                         kbox, karea, (uint32_t*)kout);
+                                         kbox, karea, (uint32_t*)kout, grid);
         if (threadIdx.x == 0) keep_cnt[seg] = nk;
         return;
     }
@@ -485,10 +533,12 @@ __global__ __launch_bounds__(1024) void k_nms_frame(LvLayout G, int lds_cap, int
     float* fout = s1_box + (size_t)f * capF * 5;
     if (total > lds_cap) {                                                        // ---- spill tier
         const int P = next_pow2(total), C = pow2_floor(lds_cap);
-        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)total * 24);
+        const int gx = (W >> GRID_SHIFT) + 1, gy = (H >> GRID_SHIFT) + 1;
+        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)total * 28 + (size_t)gx * gy * 4);
         if (!w) { if (threadIdx.x == 0) n1[f] = 0; return; }
         uint64_t* gk = (uint64_t*)w; uint32_t* gi = (uint32_t*)(gk + P);
         float4* kbox = (float4*)(gi + P); float* karea = (float*)(kbox + total); uint32_t* kid = (uint32_t*)(karea + total);
+        const KeptGrid grid{(int*)(kid + total) + total, (int*)(kid + total), gx, gy};
         for (int e = threadIdx.x; e < P; e += blockDim.x) {
             uint64_t k = ~0ull; uint32_t g = 0;
             if (e < total) fill(e, k, g);
@@ -498,7 +548,7 @@ __global__ __launch_bounds__(1024) void k_nms_frame(LvLayout G, int lds_cap, int
         big_bitonic(gk, gi, P, S.key, S.id, C);
         const int nk = big_greedy<false>(S, C, gi, total, 0.7f,
                                          [&](uint32_t id) { const Cand& c = frec[id]; return make_float4(c.x1, c.y1, c.x2, c.y2); },
-                                         kbox, karea, kid);
+                                         kbox, karea, kid, grid);
         int out = 0;                                                              // rows written so far (ordered compaction, chunk by chunk)
         for (int base = 0; base < nk; base += C) {
             const int nc = nk - base < C ? nk - base : C;
@@ -623,10 +673,12 @@ __global__ __launch_bounds__(1024) void k_stage2_post(int lds_cap, int capF, int
     __syncthreads();
     if (cnt > lds_cap) {                                                          // ---- spill tier
         const int C = pow2_floor(lds_cap);
-        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)cnt * 24);
+        const int gx = (W >> GRID_SHIFT) + 1, gy = (H >> GRID_SHIFT) + 1;
+        char* w = spill_alloc(sp, (size_t)P * 12 + (size_t)cnt * 28 + (size_t)gx * gy * 4);
         if (!w) { if (threadIdx.x == 0) n2[f] = 0; return; }
         uint64_t* gk = (uint64_t*)w; uint32_t* gi = (uint32_t*)(gk + P);
         float4* kbox = (float4*)(gi + P); float* karea = (float*)(kbox + cnt); uint32_t* kid = (uint32_t*)(karea + cnt);
+        const KeptGrid grid{(int*)(kid + cnt) + cnt, (int*)(kid + cnt), gx, gy};
         int mine = 0;
         for (int i = threadIdx.x; i < P; i += blockDim.x) {
             uint64_t k = ~0ull;
@@ -644,7 +696,7 @@ __global__ __launch_bounds__(1024) void k_stage2_post(int lds_cap, int capF, int
         big_bitonic(gk, gi, P, S.key, S.id, C);
         const int nk = big_greedy<false>(S, C, gi, m, 0.7f,
                                          [&](uint32_t i) { const float* b = fb + 5 * i; return make_float4(b[0], b[1], b[2], b[3]); },
-                                         kbox, karea, kid);
+                                         kbox, karea, kid, grid);
         int out = 0;
         for (int base = 0; base < nk; base += C) {
             const int nc = nk - base < C ? nk - base : C;
@@ -758,7 +810,8 @@ __global__ __launch_bounds__(1024) void k_stage3_post(int lds_cap, int capF, int
         if (m == 0) { if (threadIdx.x == 0) n3[f] = 0; return; }
         big_bitonic(gk, gi, P, S.key, S.id, C);
         const int nk = big_greedy<true>(S, C, gi, m, 0.7f,
-                                        [&](uint32_t i) { return stage3_box(fb + 5 * i, logits + 16 * i + 2); }, kbox, karea, kid);
+                                        [&](uint32_t i) { return stage3_box(fb + 5 * i, logits + 16 * i + 2); }, kbox, karea, kid,
+                                        KeptGrid{nullptr, nullptr, 0, 0});
         for (int r = threadIdx.x; r < nk; r += blockDim.x) {
             const int i = (int)kid[r];
             const float4 bb = kbox[r];
@@ -1073,10 +1126,10 @@ static void plan_lists(trl_ctx* c, int L) {
     if (wantF < 4) wantF = 4;
     B.capF = (int)((wantF + 3) & ~3ll);
 }
-static size_t spill_need(long long cnt) {   // workspace of one spilled list of cnt entries (k_nms_level .. k_stage3_post)
+static size_t spill_need(long long cnt, int W, int H) {   // workspace of one spilled list of cnt entries (k_nms_level .. k_stage3_post)
     long long P = 2;
     while (P < cnt) P <<= 1;
-    return (size_t)(P * 12 + cnt * 24 + 256);
+    return (size_t)(P * 12 + cnt * 28 + ((long long)(W >> 5) + 1) * ((H >> 5) + 1) * 4 + 256);
 }
 
 // detect_face() stages 1-3 for n frames; results stay in c->cb
@@ -1092,8 +1145,8 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     size_t spill = c->spill_hint;
     {
         size_t per_frame = 0;
-        for (int l = 0; l < L; l++) if (G.capl[l] > lds_full) per_frame += spill_need(G.capl[l]);
-        if (capF > lds_full) per_frame += 3 * spill_need(capF);
+        for (int l = 0; l < L; l++) if (G.capl[l] > lds_full) per_frame += spill_need(G.capl[l], W, H);
+        if (capF > lds_full) per_frame += 3 * spill_need(capF, W, H);
         size_t up_front = per_frame * (size_t)n;
         if (up_front > (8ull << 30)) up_front = 8ull << 30;
         if (up_front > spill) spill = up_front;
@@ -1225,10 +1278,10 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     {
         const int small_cap = full_l < lds_small ? full_l : lds_small;
         const size_t sm_s = Smem::bytes(small_cap);
-        k_nms_level<<<n * L, 256, sm_s, s>>>(G, small_cap, 0, small_cap == max_capl ? 1 : 0, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags, sp);
+        k_nms_level<<<n * L, 256, sm_s, s>>>(G, small_cap, 0, small_cap == max_capl ? 1 : 0, W, H, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags, sp);
         TRL_LAUNCH_CHECK();
         if (small_cap < max_capl) {
-            k_nms_level<<<n * L, th_l, sm_l, s>>>(G, full_l, small_cap + 1, 1, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags, sp);
+            k_nms_level<<<n * L, th_l, sm_l, s>>>(G, full_l, small_cap + 1, 1, W, H, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags, sp);
             TRL_LAUNCH_CHECK();
         }
     }

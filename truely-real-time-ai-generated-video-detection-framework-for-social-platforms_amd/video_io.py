@@ -278,8 +278,9 @@ class AviMjpegReader:
         self.width = self.height = 0
         self.fps_f, self.n, self.codec = 0.0, 0, b""
         self.frames: list = []                       # (file offset, size)
-        pos = 12
-        while pos + 8 <= fsize:
+        pos, top = 12, 0
+        while pos + 8 <= fsize and top < 65536:      # (a sane file has a handful of top-level chunks: a hostile one cannot make this spin)
+            top += 1
             self.f.seek(pos)
             cid, csz = struct.unpack("<4sI", self.f.read(8))
             if cid == b"LIST":
@@ -337,11 +338,14 @@ class AviMjpegReader:
         self.f.seek(off)
         try:
             im = Image.open(io.BytesIO(self.f.read(size))).convert("RGB")
-        except Exception:  # noqa: BLE001 - a damaged frame ends the clip like a failed cap.read()
+        except Exception as e:  # noqa: BLE001 - a damaged frame ends the clip like a failed cap.read() -- but not silently
+            print(f"Warning: frame {self.i} of {self.n} cannot be decoded ({e}): the clip is analysed up to it")
             return False, None
         self.i += 1
         a = np.asarray(im, np.uint8)
         if a.shape[0] != self.height or a.shape[1] != self.width:
+            print(f"Warning: frame {self.i - 1} of {self.n} is {a.shape[1]}x{a.shape[0]}, the header says {self.width}x{self.height}: "
+                  f"the clip is analysed up to it")
             return False, None
         return True, np.ascontiguousarray(a[:, :, ::-1])
 
@@ -444,6 +448,8 @@ def open_writer(path, fps, size, like_raw: bool = False):
         return RawWriter(path, fps, size)
     if cv2 is not None:  # pragma: no cover
         return cv2.VideoWriter(path, cv2.VideoWriter_fourcc(*"H264"), fps, size)
+    if not str(path).lower().endswith(".avi"):       # the server names the file *.mp4 and serves it as video/mp4: say what it really is
+        print(f"Note: OpenCV is not installed, {os.path.basename(str(path))} is written as Motion-JPEG in an AVI container (not H.264)")
     return AviMjpegWriter(path, fps, size)
 
 
