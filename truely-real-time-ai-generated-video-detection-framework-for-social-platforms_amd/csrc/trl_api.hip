@@ -366,7 +366,7 @@ static int mtcnn_detect_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, 
     c->scratch_after_cascade = 0;
     for (int attempt = 0;; attempt++) {
         TRL_HIP(hipEventRecord(c->ev_call0, s));
-        TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s));
+        TRL_CHECK(trl_cascade_detect(c, d_frames, n, H, W, s, attempt ? c->resume_stage : 0));
         // scratch for the model.py-only outputs
         float* box0 = (float*)c->arena.alloc((size_t)n * 16); float* prob0 = (float*)c->arena.alloc((size_t)n * 4);
         int32_t* rect = (int32_t*)c->arena.alloc((size_t)n * 16); uint8_t* valid = (uint8_t*)c->arena.alloc((size_t)n);
@@ -406,8 +406,8 @@ static int detect_embed_enqueue(trl_ctx* c) {
     hipStream_t s = (hipStream_t)q.stream;
     const int n = q.n, H = q.H, W = q.W;
     const int S = c->cfg.embed_mode == 0 ? 80 : 160;
-    TRL_HIP(hipEventRecord(c->ev_call0, s));
-    TRL_CHECK(trl_cascade_detect(c, q.frames, n, H, W, s));
+    if (!q.attempt) TRL_HIP(hipEventRecord(c->ev_call0, s));
+    TRL_CHECK(trl_cascade_detect(c, q.frames, n, H, W, s, q.attempt ? c->resume_stage : 0));
     float* pts0 = nullptr;
     if (c->cfg.embed_mode == 3) {                // the largest face's landmarks steer the aligned crop
         pts0 = (float*)c->arena.alloc((size_t)n * 40);

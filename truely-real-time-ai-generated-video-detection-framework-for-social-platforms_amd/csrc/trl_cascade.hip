@@ -1133,11 +1133,14 @@ static size_t spill_need(long long cnt, int W, int H) {   // workspace of one sp
 }
 
 // detect_face() stages 1-3 for n frames; results stay in c->cb
-int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipStream_t s) {
+// `resume` = 2 / 3: re-run of a call whose R-Net / O-Net batch capacity was too small -- everything up to that stage is intact in
+// the cascade arena (the lists, the stage boxes, the counts), so the attempt starts at stage 2 / 3 instead of at the pyramid.
+int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipStream_t s, int resume) {
     const int L = trl_compute_levels(c, H, W);
     CascadeBufs& B = c->cb;
+    if (resume >= 2 && !(B.flags && B.n == n && B.L == L && B.H == H && B.W == W && L > 0)) resume = 0;   // nothing to resume from
     B.n = n; B.L = L; B.H = H; B.W = W;
-    plan_lists(c, L);
+    if (!resume) plan_lists(c, L);
     const LvLayout& G = B.lay;
     const int capF = B.capF;
     const int lds_full = c->nms_full, lds_small = c->nms_small < c->nms_full ? c->nms_small : c->nms_full;
@@ -1153,8 +1156,16 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     }
     Arena& A = c->arena;      // cascade lists: live for the whole call (and for the debug hooks after it)
     Arena& X = c->scratch;    // activations: reset between stages
+    if (resume) {
+        A.off = B.arena_mark;                                // the API layer's per-frame outputs are allocated again behind the lists
+        // the stages that run again report afresh (the stage-2 total of a resume at stage 3 stays: it is complete)
+        TRL_HIP(hipMemsetAsync(B.flags + FLG_T3, 0, 4, s));
+        TRL_HIP(hipMemsetAsync(B.flags + FLG_T3N, 0, 4, s));
+        if (resume == 2) { TRL_HIP(hipMemsetAsync(B.flags + FLG_T2, 0, 4, s)); TRL_HIP(hipMemsetAsync(B.flags + FLG_T2N, 0, 4, s)); }
+    }
     const size_t need = (size_t)n * ((size_t)G.S * (sizeof(Cand) + 4) + (size_t)L * 8) + (size_t)n * capF * (5 * 3 + 10 + 8) * 4 +
                         (size_t)n * 1024 + spill + (1u << 20);   // + the API layer's per-frame outputs (box0, prob0, rect, valid, pts0)
+    if (!resume) {
     TRL_CHECK(trl_ensure(c, A, need));
     A.reset();
     B.lvl_cnt = (int32_t*)A.alloc((size_t)n * L * 4);
@@ -1170,7 +1181,9 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     B.spill = spill ? (char*)A.alloc(spill) : nullptr;
     B.spill_cap = B.spill ? spill : 0;
     if (!B.flags || (spill && !B.spill)) { trl_set_error("cascade workspace allocation failed"); return TRL_ERR_STATE; }
+    B.arena_mark = A.off;
     TRL_HIP(hipMemsetAsync(B.flags, 0, TRL_NFLAGS * 4, s));
+    }
     const Spill sp{B.spill, (unsigned long long)B.spill_cap, B.flags};
     if (L == 0) {
         // min(H, W) * 12 / min_face_size < 12: detect_face() builds no scale at all and returns no boxes (the frame is smaller
@@ -1183,10 +1196,10 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         if (c->scratch_after_cascade) TRL_CHECK(trl_ensure(c, X, c->scratch_after_cascade));   // the crops + embedder of the same call
         return TRL_OK;
     }
-    TRL_HIP(hipMemsetAsync(B.lvl_cnt, 0, (size_t)n * L * 4, s));
+    if (!resume) TRL_HIP(hipMemsetAsync(B.lvl_cnt, 0, (size_t)n * L * 4, s));
 
     // ---- stage 1: PNet over the pyramid ----------------------------------------------------------
-    c->pnet_ev_used = 0;
+    if (!resume) c->pnet_ev_used = 0;
     X.reset();
     int chunk[32];
     const bool fused = c->cfg.pnet_mode == 0 && L <= 16;   // the fused launch carries 16 level descriptors; taller pyramids (a
@@ -1231,7 +1244,9 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
         if (c->scratch_after_cascade > need_x) need_x = c->scratch_after_cascade;   // the embedder that follows in the same call
         TRL_CHECK(trl_ensure(c, X, need_x));
     }
-    if (fused) {
+    if (resume) {
+        // stage 1 is intact
+    } else if (fused) {
         // fused path: pyramid kernel + ONE persistent PNet launch over every (frame, level, tile)
         std::pair<hipEvent_t, hipEvent_t>*pa, *pb;
         c->pnet_ev.reserve(64);   // next_ev hands out pointers into the vector: no reallocation below
@@ -1275,7 +1290,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     TRL_CHECK(set_dyn_smem(k_nms_frame, sm_f));
     TRL_CHECK(set_dyn_smem(k_stage2_post, sm_f));
     TRL_CHECK(set_dyn_smem(k_stage3_post, sm_f));
-    {
+    if (!resume) {
         const int small_cap = full_l < lds_small ? full_l : lds_small;
         const size_t sm_s = Smem::bytes(small_cap);
         k_nms_level<<<n * L, 256, sm_s, s>>>(G, small_cap, 0, small_cap == max_capl ? 1 : 0, W, H, B.lvl_cnt, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.flags, sp);
@@ -1285,14 +1300,17 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
             TRL_LAUNCH_CHECK();
         }
     }
-    k_nms_frame<<<n, th_f, sm_f, s>>>(G, full_f, capF, W, H, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.n1, B.s1_box, B.flags, sp);
-    TRL_LAUNCH_CHECK();
+    if (!resume) {
+        k_nms_frame<<<n, th_f, sm_f, s>>>(G, full_f, capF, W, H, B.lvl_rec, B.lvl_keep_cnt, B.lvl_keep_idx, B.n1, B.s1_box, B.flags, sp);
+        TRL_LAUNCH_CHECK();
+    }
 
     // ---- stage 2: RNet ------------------------------------------------------------------------------
     // No host round trip: the candidate total stays on the device (off2[n]).  Launches are sized by an optimistic capacity
     // (c->cap_t2, from earlier calls) and workgroups past the real total exit at once; if the total exceeds the capacity a
     // flag is raised and the caller re-runs the call with a larger one (trl_cascade_run).
     const int cap2 = c->cap_t2, cap3 = c->cap_t3;
+    if (resume < 3) {
     k_scan_counts<<<1, 256, 0, s>>>(B.n1, n, B.off2, cap2, B.flags, 0);
     TRL_LAUNCH_CHECK();
     k_build_map<<<n, 64, 0, s>>>(B.n1, B.off2, B.s1_box, capF, W, H, B.cbox);
@@ -1313,6 +1331,7 @@ int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     }
     k_stage2_post<<<n, th_f, sm_f, s>>>(full_f, capF, cap2, W, H, c->cfg.thr1, B.n1, B.s1_box, B.off2, out6, B.n2, B.s2_box, sp);
     TRL_LAUNCH_CHECK();
+    }
 
     // ---- stage 3: ONet --------------------------------------------------------------------------------
     k_scan_counts<<<1, 256, 0, s>>>(B.n2, n, B.off3, cap3, B.flags, 1);
@@ -1359,6 +1378,7 @@ int trl_cascade_check(trl_ctx* c, int n, int* retry) {
     const int32_t* f = c->h_pinned + 4;
     const int L = c->cb.L;
     *retry = 0;
+    c->resume_stage = 0;
     unsigned long long spill_used = 0;
     memcpy(&spill_used, f + FLG_SPILL_CUR, 8);
     if (f[FLG_LEVEL]) {                                  // every later stage ran on truncated lists: their totals mean nothing
@@ -1383,8 +1403,8 @@ int trl_cascade_check(trl_ctx* c, int n, int* retry) {
     if (f[FLG_FRAME]) { c->frame_hint = 1.25f * (float)f[FLG_FRAME_MAX] + 4.f; *retry = 1; return TRL_OK; }
     // keep ~25 % headroom over the largest batch seen, so a drifting clip rarely needs a second attempt
     const float want2 = 1.25f * (float)f[FLG_T2N] / (float)n + 1.f, want3 = 1.25f * (float)f[FLG_T3N] / (float)n + 1.f;
-    if (f[FLG_T2]) { c->t2_per_frame = want2; *retry = 1; }       // stage 3 ran on an incomplete stage 2: its total is meaningless
-    else if (f[FLG_T3]) { c->t3_per_frame = want3; *retry = 1; }
+    if (f[FLG_T2]) { c->t2_per_frame = want2; *retry = 1; c->resume_stage = 2; }       // stage 3 ran on an incomplete stage 2: its total is meaningless
+    else if (f[FLG_T3]) { c->t3_per_frame = want3; *retry = 1; c->resume_stage = 3; }  // (stages 1 / 1-2 are intact: the re-run starts behind them)
     if (!*retry) {
         // follow the content: grow at once, decay 3 % per call towards what recent batches needed (never below the start values),
         // so one crowded batch does not inflate every later call's launches and workspace for the life of the context

@@ -38,6 +38,7 @@ struct CascadeBufs {   // device pointers into the arena, valid until the next c
     int32_t* off2 = nullptr; int32_t* off3 = nullptr; // [n+1] exclusive scans of n1 / n2
     int32_t* cbox = nullptr;     // [n*capF][8]: candidate t of the current stage = {frame, y0, x0, ih, iw, 0, 0, 0} (pad()'s crop window)
     int32_t* flags = nullptr;        // [TRL_NFLAGS]: see trl_cascade.hip
+    size_t arena_mark = 0;           // arena offset behind the cascade's own blocks (where a resumed attempt re-allocates the API outputs)
     char* spill = nullptr;           // global-memory workspace of the NMS spill tier (lists longer than the LDS tier)
     size_t spill_cap = 0;
 };
@@ -80,6 +81,7 @@ struct trl_ctx {
     int nms_small = 512, nms_full = 2048;   // LDS tiers of the sort + NMS kernels (candidates); longer lists take the spill tier
                                             // (trl_debug_nms_tiers lowers them so that small test inputs reach every tier)
     int last_attempts = 0;           // attempts the last call took (test hook)
+    int resume_stage = 0;            // 2 / 3: the next attempt of the call in progress starts at that stage (trl_cascade_check)
     size_t scratch_after_cascade = 0;   // scratch bytes the rest of the call needs (crops + FaceNet): sized with the cascade's
     int rnet_front_mode = -1, onet_front_mode = -1;   // conv1 PReLU slope class (trl_front.hip), -1 = not yet classified
     // the call queued by trl_detect_embed_begin / trl_detect_crop_begin and not yet finished by trl_detect_embed_end
@@ -113,7 +115,7 @@ int trl_run_pnet_generic(trl_ctx* c, const float* d_level, int nf, int h, int w,
 size_t trl_pnet_generic_bytes(int nf, int h, int w);
 
 // cascade (trl_cascade.hip)
-int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipStream_t s);
+int trl_cascade_detect(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, hipStream_t s, int resume = 0);
 int trl_cascade_finish(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W, float* d_boxes, float* d_probs, float* d_points,
                        int32_t* d_counts, float* d_box0, float* d_prob0, int32_t* d_rect, uint8_t* d_valid, float* d_pts0, hipStream_t s);
 int trl_cascade_check(trl_ctx* c, int n, int* retry);   // after the call's stream synchronisation
