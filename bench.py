@@ -187,6 +187,10 @@ def parse_args(argv=None):
                          "the device, every kernel runs alone and the HIP event pair around a launch is its duration.  2: +3 %% "
                          "frames/s (the head of one persistent PNet launch fills the tail of the other's), but then the pair also "
                          "counts the wait behind the other context's launch (profiles/round4_pnet_gate_ab.txt)")
+    ap.add_argument("--pnet-gate", type=int, default=0, choices=[0, 1],
+                    help="with --in-flight >= 2.  1: a fused PNet launch waits for the end of the device's previous call (it runs alone, the "
+                         "event pair is its duration; the pyramid kernels in front of it overlap that call's narrow kernels): +1.3 %% over one "
+                         "batch in flight.  0 (default): launches of different contexts are left to the hardware queues: +3 %%, no clean clock")
     ap.add_argument("--embed-group", type=int, default=8,
                     help="consecutive steps whose crops the decoupled embedder embeds in ONE InceptionResnetV1 call (trl_detect_crop per "
                          "step into a ring, then one trl_facenet_embed_masked): same bits, ~100 small launches amortised over G x 256 faces")
@@ -284,6 +288,7 @@ def main():
     F = max(1, args.in_flight)
     ekw = dict(device=local, pnet_mode=args.pnet_mode, min_face_size=cfg["min_face"], embed_precision=cfg["embed"])
     engs = [Engine(blob, **ekw) for _ in range(F)]   # one context + workspace per batch in flight
+    engs[0].option("pnet_gate", args.pnet_gate)
     streams = [torch.cuda.Stream(dev) for _ in range(F)]
     eng = engs[0]
     drift_eng = Engine(blob, device=local) if F > 1 else eng      # the main thread's context (drift kernels)

@@ -185,7 +185,9 @@ int  trl_debug_list_stats(trl_ctx* ctx, long long* h_out8);
 /* test hooks that used to be environment variables (the library reads none; experiment switches exist only in a `make TUNING=1`
  * build): key "rnet_chunk" / "onet_chunk" = candidates per R-/O-Net launch set of this context (>= 16: small inputs then run
  * the multi-chunk path); "no_fnconv" (process-wide, ctx may be NULL) = FaceNet's small maps through the generic conv kernels,
- * value 0 restores the default.  Results never depend on them. (ABI v7) */
+ * value 0 restores the default; "pnet_gate" (process-wide, default 0) = 1: a fused PNet launch waits for the end of the previous
+ * call queued on its device by ANY context, so that with several contexts in flight it runs alone (a timing aid: the HIP event
+ * pair of trl_debug_timings is then the launch's duration).  Results never depend on them. (ABI v7) */
 int  trl_debug_option(trl_ctx* ctx, const char* key, int value);
 /* test hook: the R-/O-Net launches are sized by optimistic per-frame candidate capacities; set them (<= 0 keeps a value) and read
  * how many attempts the last call took (a too-small capacity makes the call re-run itself with a larger one) */

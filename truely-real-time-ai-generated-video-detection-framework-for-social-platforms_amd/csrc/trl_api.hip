@@ -9,6 +9,30 @@
 
 static thread_local char g_err[512] = "";
 int g_trl_no_fnconv = 0;
+int g_trl_pnet_gate = 0;
+
+#include <mutex>
+namespace {
+std::mutex g_gate_mu;
+hipEvent_t g_gate_ev[64] = {};
+bool g_gate_set[64] = {};
+}
+int trl_gate_wait(trl_ctx* c, hipStream_t s) {
+    const int d = c->cfg.device;
+    if (!g_trl_pnet_gate || d < 0 || d >= 64) return TRL_OK;
+    std::lock_guard<std::mutex> lk(g_gate_mu);
+    if (g_gate_set[d]) TRL_HIP(hipStreamWaitEvent(s, g_gate_ev[d], 0));
+    return TRL_OK;
+}
+int trl_gate_record(trl_ctx* c, hipStream_t s) {
+    const int d = c->cfg.device;
+    if (!g_trl_pnet_gate || d < 0 || d >= 64) return TRL_OK;
+    std::lock_guard<std::mutex> lk(g_gate_mu);
+    if (!g_gate_ev[d]) TRL_HIP(hipEventCreateWithFlags(&g_gate_ev[d], hipEventDisableTiming));
+    TRL_HIP(hipEventRecord(g_gate_ev[d], s));
+    g_gate_set[d] = true;
+    return TRL_OK;
+}
 void trl_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -376,6 +400,7 @@ static int mtcnn_detect_impl(trl_ctx* c, const uint8_t* d_frames, int n, int H, 
         if (d_points) TRL_HIP(hipMemsetAsync(d_points, 0, (size_t)n * c->cfg.max_faces * 40, s));
         TRL_CHECK(trl_cascade_finish(c, d_frames, n, H, W, d_boxes, d_probs, d_points, d_counts, box0, prob0, rect, valid, nullptr, s));
         TRL_HIP(hipEventRecord(c->ev_call1, s));
+        TRL_CHECK(trl_gate_record(c, s));
         TRL_HIP(hipStreamSynchronize(s));             // the call's one host synchronisation
         int retry = 0;
         TRL_CHECK(trl_cascade_check(c, n, &retry));
@@ -394,7 +419,8 @@ int trl_facenet_embed(trl_ctx* c, const float* d_faces, int n, int h, int w, flo
     TRL_HIP(hipSetDevice(c->cfg.device));
     c->scratch.reset();
     TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * ((size_t)h * w * 110 + 400000) * 4 + (8u << 20)));
-    return trl_run_facenet(c, d_faces, n, h, w, nullptr, d_emb, (hipStream_t)stream);
+    TRL_CHECK(trl_run_facenet(c, d_faces, n, h, w, nullptr, d_emb, (hipStream_t)stream));
+    return trl_gate_record(c, (hipStream_t)stream);
 }
 
 // model.py:47-58 (detect, largest box, crop + resize) and optionally :59 (embed).  d_faces_out != null: the crops are written there
@@ -425,6 +451,7 @@ static int detect_embed_enqueue(trl_ctx* c) {
     else TRL_CHECK(trl_launch_crop_area_std(q.frames, n, H, W, q.rect, q.valid, S, c->cfg.embed_mode == 2, faces, s));
     if (!q.faces_out) TRL_CHECK(trl_run_facenet(c, faces, n, S, S, q.valid, q.emb, s));
     TRL_HIP(hipEventRecord(c->ev_call1, s));
+    TRL_CHECK(trl_gate_record(c, s));
     return TRL_OK;
 }
 
@@ -499,7 +526,8 @@ int trl_facenet_embed_masked(trl_ctx* c, const float* d_faces, const uint8_t* d_
     TRL_HIP(hipSetDevice(c->cfg.device));
     c->scratch.reset();
     TRL_CHECK(trl_ensure(c, c->scratch, (size_t)n * ((size_t)h * w * 110 + 400000) * 4 + (8u << 20)));
-    return trl_run_facenet(c, d_faces, n, h, w, d_valid, d_emb, (hipStream_t)stream);
+    TRL_CHECK(trl_run_facenet(c, d_faces, n, h, w, d_valid, d_emb, (hipStream_t)stream));
+    return trl_gate_record(c, (hipStream_t)stream);
 }
 
 int trl_drift_score(trl_ctx* c, const float* d_emb, const uint8_t* d_valid, int n, long long frame_count, int fps, float* d_sims,
@@ -732,6 +760,7 @@ int trl_debug_list_stats(trl_ctx* c, long long* h_out8) {
 int trl_debug_option(trl_ctx* c, const char* key, int value) {
     if (!key) { trl_set_error("null key"); return TRL_ERR_INVALID; }
     if (!strcmp(key, "no_fnconv")) { g_trl_no_fnconv = value ? 1 : 0; return TRL_OK; }
+    if (!strcmp(key, "pnet_gate")) { g_trl_pnet_gate = value ? 1 : 0; return TRL_OK; }
     TRL_CHECK(check_idle(c));
     if (!strcmp(key, "rnet_chunk") && value >= 16) { c->rnet_chunk = value; return TRL_OK; }
     if (!strcmp(key, "onet_chunk") && value >= 16) { c->onet_chunk = value; return TRL_OK; }

@@ -97,6 +97,14 @@ struct trl_ctx {
     struct { int nlev = 0, own0 = 0, band_cols = 0, strip_rows = 0, n_bands = 0, n_strips = 0; } pyr_fine;
 };
 
+// Optional device-wide ordering of the wide phases of different contexts (trl_api.hip; OFF by default, trl_debug_option
+// "pnet_gate"): a fused PNet launch waits for the END of the most recent call queued on the device, whichever context queued it,
+// so it runs alone (its HIP event pair is its duration) while the memory-bound pyramid kernels in front of it overlap the previous
+// call's narrow R-/O-Net / embedder kernels.  Measured with two contexts in flight: 18.8 k frames/s and a clean clock, against
+// 19.1 k with the launches left to the hardware queues and 18.6 k with one context (profiles/round4_pnet_gate_ab.txt).
+int trl_gate_wait(trl_ctx* c, hipStream_t s);      // before the fused PNet launch
+int trl_gate_record(trl_ctx* c, hipStream_t s);    // behind the last kernel of a call
+extern int g_trl_pnet_gate;                        // trl_debug_option("pnet_gate"): 0 (default) / 1
 int trl_ensure(trl_ctx* c, Arena& a, size_t bytes);   // grow (never while blocks of `a` are live)
 const DevW* trl_w(trl_ctx* c, const std::string& name);
 const DevV* trl_v(trl_ctx* c, const std::string& name);

@@ -1811,6 +1811,10 @@ int trl_pnet_fused_all(trl_ctx* c, const uint8_t* d_frames, int n, int H, int W,
     if (grid > ((total_tiles + 7) / 8) * 8) grid = ((total_tiles + 7) / 8) * 8;
     if (grid < 8) grid = 8;
     TRL_HIP(hipMemsetAsync(c->pnet_cursor, 0, 8 * sizeof(int32_t), s));
+    // The persistent grid fills every CU: it waits for the end of the device's previous call (another context's cascade tail or
+    // embedder) and then runs alone, so the event pair below is its duration; the pyramid kernels queued in front of it are
+    // memory-bound and DO overlap that call's narrow kernels (trl_gate_wait, trl_api.hip).
+    TRL_CHECK(trl_gate_wait(c, s));
     if (ev) TRL_HIP(hipEventRecord(ev[2], s));   // the event pair brackets the kernel alone (HIP events on the launch's stream)
     static const int xlds = trl_tune_int("TRL_PNET_XLDS", 0);   // experiment: unused dynamic LDS, lowers the resident workgroups per CU
     // instantiation: slopes all <= 1 or not, a negative conv1 slope or not, diagnostics (TRL_PNET_CLOCK / TRL_PNET_SKIP) or not
