@@ -438,6 +438,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if embed_eng is not None:
+        # Set-up, not a step: size the decoupled embedder's workspace for a FULL group before anything is timed.  The warm-up's
+        # W steps end in a partial group (W < G), so the first full group -- and with it a hipFree + hipMalloc of ~10 GB inside
+        # trl_ensure -- would otherwise fall into the timed region (usually milliseconds, occasionally hundreds on a busy host).
+        Sf = 80 if eng.cfg.embed_mode == 0 else 160
+        Gf = max(1, args.embed_group)
+        embed_eng.embed_faces(torch.zeros((Gf * n, Sf, Sf, 3), dtype=torch.float32, device=dev), torch.ones((Gf * n,), dtype=torch.uint8, device=dev))
+        torch.cuda.synchronize()
     if args.warmup > 0:
         run_steps(max(args.warmup, F))
     fence()

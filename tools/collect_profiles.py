@@ -62,6 +62,10 @@ def main():
         src = os.path.join(SRC, name)
         if os.path.exists(src) and os.path.getsize(src) > 0:
             shutil.copy(src, os.path.join(DST, f"{tag}_{name}"))
+    for name in ("crowded_timing.jsonl", "run_wall_time.json"):
+        src = os.path.join(SRC, name)
+        if os.path.exists(src) and os.path.getsize(src) > 0:
+            shutil.copy(src, os.path.join(DST, f"{tag}_{name}"))
     for name in ("facenet_ms.txt", "facenet_stamps.txt"):
         src = os.path.join(SRC, name)
         if os.path.exists(src):

@@ -46,3 +46,6 @@ TRUELY_HIP_LIB=$TUNE_LIB TRL_PNET_CLOCK=1 timeout -k 10 300 python bench.py --st
 bash tools/pnet_phase_pmc.sh > /dev/null 2>&1; cp gpurun_out/pnet_phase_pmc.txt $O/pnet_phase_pmc.txt
 bash tools/front_ablation.sh > /dev/null 2>&1; cp gpurun_out/front_ablation.txt $O/front_ablation.txt
 echo "phase evidence done"
+timeout -k 10 300 python tools/crowded_timing.py --pathological > $O/crowded_timing.jsonl 2> $O/crowded_timing.err
+timeout -k 10 600 python tools/run_wall_time.py $O/run_wall_time.json --long > $O/run_wall_time.log 2>&1
+echo "crowded content + run() wall time done"

@@ -167,15 +167,15 @@ class Overlapped:
     def _slot_views(self, i, n):
         ring = self.ring
         if ring["faces"] is None:
-            need = self.R * n * (self.S * self.S * 3 * 4 + 1)
-            free, _total = torch.cuda.mem_get_info(self.dev)
-            if need > free // 2:
-                raise RuntimeError(f"the crop ring of embed_group={self.G} needs {need >> 20} MiB ({self.R} slots of {n} crops), "
-                                   f"{free >> 20} MiB are free: lower embed_group or the batch size")
             ring["n"] = n
             with torch.cuda.stream(torch.cuda.default_stream(self.dev)):     # shared by every stream of the run: not owned by one of them
-                ring["faces"] = torch.empty((self.R, n, self.S, self.S, 3), dtype=torch.float32, device=self.dev)
-                ring["valid"] = torch.empty((self.R, n), dtype=torch.uint8, device=self.dev)
+                try:                                     # (no hipMemGetInfo query here: on a shared host that ioctl can stall for 100s of ms)
+                    ring["faces"] = torch.empty((self.R, n, self.S, self.S, 3), dtype=torch.float32, device=self.dev)
+                    ring["valid"] = torch.empty((self.R, n), dtype=torch.uint8, device=self.dev)
+                except torch.cuda.OutOfMemoryError as e:
+                    need = self.R * n * (self.S * self.S * 3 * 4 + 1)
+                    raise RuntimeError(f"the crop ring of embed_group={self.G} needs {need >> 20} MiB ({self.R} slots of {n} crops): "
+                                       f"lower embed_group or the batch size") from e
         if n > ring["n"]:
             raise ValueError("batches must not grow after the first one")
         k = i % self.R
