@@ -35,13 +35,15 @@ class GatherHandle:
     """An all-gather of result rows in flight (``allgather_embeddings_async``).  ``wait()`` returns the time-ordered rows; with RCCL
     it makes the CURRENT STREAM wait for the collective (the host does not block), with gloo it blocks the host."""
 
-    def __init__(self, work, out, sizes, m, extra):
+    def __init__(self, work, out, sizes, m, extra, pay=None):
         self.work, self.out, self.sizes, self.m, self.extra = work, out, sizes, m, extra
+        self.pay = pay                                   # the send buffer stays alive until the collective has been waited for
 
     def wait(self):
         if self.work is not None:
             self.work.wait()
             self.work = None
+            self.pay = None
         out, sizes, m = self.out, self.sizes, self.m
         if all(s == m for s in sizes):
             rows = out
@@ -81,7 +83,7 @@ def allgather_embeddings_async(emb: torch.Tensor, valid: torch.Tensor, counts: O
         pay[:n_loc, 517:521] = rect.to(torch.int32).contiguous().view(torch.float32)
     out = torch.empty((world * m, _ROW), dtype=torch.float32, device=emb.device)
     work = dist.all_gather_into_tensor(out, pay, group=group, async_op=True)
-    return GatherHandle(work, out, sizes, m, box is not None or rect is not None)
+    return GatherHandle(work, out, sizes, m, box is not None or rect is not None, pay)
 
 
 def allgather_embeddings(emb: torch.Tensor, valid: torch.Tensor, counts: Optional[Sequence[int]] = None, group=None,
