@@ -1637,6 +1637,179 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(const uint8_t* __restric
     }
 }
 
+// ---- the same pass with WAVE-local ownership, for frames wider than one 4096-byte band (round 4) -------------------------------
+// k_pyramid_stream covers a whole row with one workgroup and therefore stops at W = 1365; 1080p and 4K frames took the per-level
+// kernels (55 launches per step at 4K, each re-reading the source).  Here a WAVE owns a segment of source columns for a band of rows
+// and never talks to another wave: lane i holds 20 consecutive bytes of the row (5 dwords + 1 for the re-alignment), the segment is
+// 64 x 20 = 1280 bytes = 426 pixels of which the last kwmax overlap the next segment, so that every bin that STARTS in the segment
+// is covered by the wave's own loads.  A completed bin row is flushed through the wave's private LDS strip (LDS operations of one
+// wave execute in order: no barrier), reduced, normalised and stored.  Integer sums: bit-identical.  (At 720p, where both apply,
+// the block-wide pass is faster -- 0.63 vs 1.11 ms: every wave pays all ~165 flush round trips alone -- so it keeps the narrow frames.)
+constexpr int SW_BYTES = 1280;           // bytes of a source row per wave
+template <int NL>
+__global__ __launch_bounds__(256) void k_pyramid_stream_w(const uint8_t* __restrict__ frames, PyrStreamArgs a, const uint32_t* __restrict__ gtab,
+                                                          PyrPx* __restrict__ pyr) {
+    __shared__ unsigned colbuf_all[4][SW_BYTES];
+    __shared__ uint32_t tab[STAB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = a.f0 + blockIdx.y;
+    const int row_bytes = a.W * 3;
+    const long long fbase = (long long)f * a.H * row_bytes;
+    const long long last_dw = ((long long)a.n_frames * a.H * row_bytes - 1) >> 2;
+    const uint32_t* base32 = reinterpret_cast<const uint32_t*>(frames);
+    int ty0[NL], tx0[NL];
+    {
+        int pos = 0;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            ty0[l] = tx0[l] = 0;
+            if (l < a.nlev) {
+                const SLevel& g = a.lv[l];
+                ty0[l] = pos; tx0[l] = pos + g.h;
+                for (int i = tid; i < g.h; i += 256) tab[pos + i] = gtab[g.ytab0 + i];
+                for (int i = tid; i < g.w; i += 256) tab[pos + g.h + i] = gtab[g.xtab0 + i];
+                pos += g.h + g.w;
+            }
+        }
+    }
+    __syncthreads();                                     // the only block barrier: from here on the waves are on their own
+    const int unit = blockIdx.x * 4 + wave;              // (row band, column segment) of this wave
+    if (unit >= a.row_bands * a.col_bands) return;
+    const int rb = unit / a.col_bands, cs = unit - rb * a.col_bands;
+    const int R0 = rb * a.rows_per_band, R1 = (R0 + a.rows_per_band < a.H) ? R0 + a.rows_per_band : a.H;
+    const int C0 = cs * a.cols_per_band, C1 = (C0 + a.cols_per_band < a.W) ? C0 + a.cols_per_band : a.W;
+    unsigned* colbuf = colbuf_all[wave];
+
+    int j[NL], jend[NL], ys[NL], ye[NL], ox0[NL], ox1[NL];
+    int yend = R0;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        j[l] = jend[l] = 0; ys[l] = ye[l] = 0x7fffffff; ox0[l] = ox1[l] = 0;
+        if (l < a.nlev) {
+            const SLevel& g = a.lv[l];
+            auto first_at_or_after = [&](int tab0, int n_out, int n_in, int pos) {   // first bin whose start >= pos
+                if (pos >= n_in) return n_out;
+                int q = (int)(((long long)pos * n_out + n_in - 1) / n_in);
+                if (q > n_out) q = n_out;
+                while (q > 0 && (int)(tab[tab0 + q - 1] & 0xFFFF) >= pos) q--;
+                while (q < n_out && (int)(tab[tab0 + q] & 0xFFFF) < pos) q++;
+                return q;
+            };
+            j[l] = __builtin_amdgcn_readfirstlane(first_at_or_after(ty0[l], g.h, a.H, R0));
+            jend[l] = __builtin_amdgcn_readfirstlane(first_at_or_after(ty0[l], g.h, a.H, R1));
+            ox0[l] = __builtin_amdgcn_readfirstlane(first_at_or_after(tx0[l], g.w, a.W, C0));
+            ox1[l] = __builtin_amdgcn_readfirstlane(first_at_or_after(tx0[l], g.w, a.W, C1));
+            if (j[l] < jend[l] && ox0[l] < ox1[l]) {
+                const uint32_t t0 = tab[ty0[l] + j[l]], t1 = tab[ty0[l] + jend[l] - 1];
+                ys[l] = __builtin_amdgcn_readfirstlane((int)(t0 & 0xFFFF)); ye[l] = __builtin_amdgcn_readfirstlane((int)(t0 >> 16));
+                const int e1 = __builtin_amdgcn_readfirstlane((int)(t1 >> 16));
+                yend = e1 > yend ? e1 : yend;
+            } else {
+                j[l] = jend[l];
+            }
+        }
+    }
+    if (unit == 0) {                                     // zero the 64-pixel padding behind each level once per frame
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+            if (l < a.nlev) {
+                const SLevel& g = a.lv[l];
+                for (int p = g.h * g.w + lane; p < g.pix_pad; p += 64)
+                    pyr_store(pyr + ((long long)f * a.pyr_stride + g.pix0 + p), make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+    }
+    if (yend <= R0) return;
+
+    unsigned ev[NL][5], od[NL][5];          // packed 16-bit column sums: bytes 0,2 / 1,3 of each of the lane's 5 dwords
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+#pragma unroll
+        for (int d = 0; d < 5; d++) { ev[l][d] = 0; od[l][d] = 0; }
+
+    // one source row: this lane's 20 bytes at byte offset C0*3 + 20*lane of row y (+ the dword behind them for the re-alignment)
+    auto load_row = [&](int y, unsigned (&w)[6], unsigned& sh) {
+        const int yy = y < a.H ? y : a.H - 1;                                    // rows past the frame are never accumulated
+        const long long o = fbase + (long long)yy * row_bytes + (long long)C0 * 3;   // scalar
+        sh = (unsigned)(o & 3);
+        const long long dw = (o >> 2) + 5 * lane;
+        if (dw + 5 <= last_dw) {
+            const u32x4_a4 v4 = *reinterpret_cast<const u32x4_a4*>(base32 + dw);
+            w[0] = v4[0]; w[1] = v4[1]; w[2] = v4[2]; w[3] = v4[3];
+            w[4] = base32[dw + 4]; w[5] = base32[dw + 5];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) w[k] = base32[dw + k <= last_dw ? dw + k : last_dw];
+        }
+    };
+    auto consume = [&](int y, const unsigned (&w)[6], unsigned sh) {
+        unsigned v[5];
+#pragma unroll
+        for (int d = 0; d < 5; d++) v[d] = __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh);
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            if (l < a.nlev && y >= ys[l] && y < ye[l]) {                         // wave-uniform
+#pragma unroll
+                for (int d = 0; d < 5; d++) { ev[l][d] += v[d] & 0x00FF00FFu; od[l][d] += (v[d] >> 8) & 0x00FF00FFu; }
+                if (y == ye[l] - 1) {
+                    // ---- the bin row is complete: column sums -> the wave's LDS strip -> horizontal bins -> normalise -> store ----
+                    const SLevel& g = a.lv[l];
+                    const int kh = ye[l] - ys[l];
+#pragma unroll
+                    for (int d = 0; d < 5; d++) {
+                        colbuf[20 * lane + 4 * d + 0] = ev[l][d] & 0xFFFFu; colbuf[20 * lane + 4 * d + 1] = od[l][d] & 0xFFFFu;
+                        colbuf[20 * lane + 4 * d + 2] = ev[l][d] >> 16;     colbuf[20 * lane + 4 * d + 3] = od[l][d] >> 16;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int ox = ox0[l] + lane; ox < ox1[l]; ox += 64) {
+                        const uint32_t tx = tab[tx0[l] + ox];
+                        const int xs = tx & 0xFFFF, xe = tx >> 16;
+                        unsigned s0 = 0, s1 = 0, s2 = 0;
+                        for (int xx = xs; xx < xe; xx++) {
+                            const unsigned* p = colbuf + (xx - C0) * 3;
+                            s0 += p[0]; s1 += p[1]; s2 += p[2];
+                        }
+                        float4 o4;
+                        o4.x = stream_norm(s0, kh, xe - xs, g); o4.y = stream_norm(s1, kh, xe - xs, g); o4.z = stream_norm(s2, kh, xe - xs, g);
+                        o4.w = 0.f;
+                        pyr_store(pyr + ((long long)f * a.pyr_stride + g.pix0 + (long long)j[l] * g.w + ox), o4);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // next owned bin of this level; consecutive bins may share this source row
+                    j[l]++;
+                    if (j[l] < jend[l]) {
+                        const uint32_t t0 = tab[ty0[l] + j[l]];
+                        ys[l] = __builtin_amdgcn_readfirstlane((int)(t0 & 0xFFFF)); ye[l] = __builtin_amdgcn_readfirstlane((int)(t0 >> 16));
+                    } else {
+                        ys[l] = ye[l] = 0x7fffffff;
+                    }
+                    const bool again = ys[l] <= y;
+#pragma unroll
+                    for (int d = 0; d < 5; d++) {
+                        ev[l][d] = again ? (v[d] & 0x00FF00FFu) : 0u;
+                        od[l][d] = again ? ((v[d] >> 8) & 0x00FF00FFu) : 0u;
+                    }
+                }
+            }
+        }
+    };
+
+    // rows in groups of four: the loads of the next group are in flight while this one is consumed
+    unsigned wb[4][6], shb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) load_row(R0 + u, wb[u], shb[u]);
+    for (int y = R0; y < yend; y += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            unsigned wc[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) wc[k] = wb[u][k];
+            const unsigned shc = shb[u];
+            if (y + u + 4 < yend) load_row(y + u + 4, wb[u], shb[u]);
+            if (y + u < yend) consume(y + u, wc, shc);
+        }
+    }
+}
+
 }  // namespace
 
 // The pyramid of all n frames (production path of both the fused PNet and the debug export below).
@@ -1710,39 +1883,56 @@ static int build_pyramid(trl_ctx* c, const uint8_t* d_frames, int n, int H, int 
     static const int bands_env = trl_tune_int("TRL_PYR_BANDS", 0);
     static const int fbands_env = trl_tune_int("TRL_PYR_FINE_BANDS", 0);
     bool streamed[16] = {};
+    static const int wide_env = trl_tune_int("TRL_PYR_STREAM_WIDE", 1);   // tuning: 0 = per-level kernels for frames wider than one band
     auto stream_group = [&](bool fine, int row_bands) -> int {
-        PyrStreamArgs sa;
-        sa.nlev = 0;
-        int stab_words = 0, kwm = 0;
-        bool picked[16] = {};
-        for (int l = 0; l < a.L; l++) {
-            const PLevel& g = a.lv[l];
-            if ((g.mode == 0) != fine) continue;
-            if (sa.nlev >= SMAXL || g.khmax > 256 || (g.kwmax + 2) * 3 > SBYTES / 2) return TRL_OK;      // group not streamable
-            picked[l] = true;
-            stab_words += g.h + g.w;
-            kwm = g.kwmax > kwm ? g.kwmax : kwm;
-            SLevel& t = sa.lv[sa.nlev++];
-            t.h = g.h; t.w = g.w; t.pix0 = g.pix0; t.pix_pad = g.pix_pad; t.ytab0 = g.ytab0; t.xtab0 = g.xtab0; t.khA = g.khA; t.kwA = g.kwA;
-            t.fastdiv = g.fastdiv; t.rkh[0] = g.rkh[0]; t.rkh[1] = g.rkh[1]; t.rkw[0] = g.rkw[0]; t.rkw[1] = g.rkw[1];
+        // the levels of the group, at most 8 per launch (register budget of the per-level column sums): each launch reads the source once
+        int lv_idx[16], nsel = 0;
+        for (int l = 0; l < a.L; l++) if ((a.lv[l].mode == 0) == fine) lv_idx[nsel++] = l;
+        const bool wide = W * 3 > SBYTES;                                       // one workgroup cannot cover the row: wave-local pass
+        if (wide && !wide_env) return TRL_OK;
+        for (int g0 = 0; g0 < nsel; g0 += 8) {
+            const int gn = nsel - g0 < 8 ? nsel - g0 : 8;
+            PyrStreamArgs sa;
+            sa.nlev = 0;
+            int stab_words = 0, kwm = 0;
+            bool ok = true;
+            for (int q = 0; q < gn; q++) {
+                const PLevel& g = a.lv[lv_idx[g0 + q]];
+                if (g.khmax > 256) ok = false;
+                stab_words += g.h + g.w;
+                kwm = g.kwmax > kwm ? g.kwmax : kwm;
+                SLevel& t = sa.lv[sa.nlev++];
+                t.h = g.h; t.w = g.w; t.pix0 = g.pix0; t.pix_pad = g.pix_pad; t.ytab0 = g.ytab0; t.xtab0 = g.xtab0; t.khA = g.khA; t.kwA = g.kwA;
+                t.fastdiv = g.fastdiv; t.rkh[0] = g.rkh[0]; t.rkh[1] = g.rkh[1]; t.rkw[0] = g.rkw[0]; t.rkw[1] = g.rkw[1];
+            }
+            sa.H = H; sa.W = W; sa.n_frames = n; sa.pyr_stride = a.pyr_stride; sa.f0 = 0;   // every source row is read once: no Infinity-Cache chunking
+            sa.row_bands = H >= 256 ? row_bands : 1;
+            sa.rows_per_band = (H + sa.row_bands - 1) / sa.row_bands;
+            if (!ok || stab_words > STAB || n > 65535) continue;                 // these levels take the per-level kernels
+            if (!wide) {
+                if ((kwm + 2) * 3 > SBYTES / 2) continue;
+                sa.col_bands = 1; sa.cols_per_band = W;
+                const dim3 sgrid(sa.row_bands * sa.col_bands, n);
+                if (sa.nlev <= 4) k_pyramid_stream<4><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
+                else k_pyramid_stream<8><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
+            } else {
+                // a wave covers 1280 bytes = 426 whole pixels of a row; the bins that start in its segment may reach kwmax further
+                sa.cols_per_band = SW_BYTES / 3 - kwm;
+                if (sa.cols_per_band < 64) continue;
+                sa.col_bands = (W + sa.cols_per_band - 1) / sa.cols_per_band;
+                sa.cols_per_band = (W + sa.col_bands - 1) / sa.col_bands;           // even segments
+                // enough waves to fill the chip (~4 k) when the batch is small: more, shorter row bands (each reads on past its end
+                // until its last bins are complete, so not shorter than 256 rows)
+                int rbn = (4096 + n * sa.col_bands - 1) / (n * sa.col_bands);
+                if (rbn > H / 256) rbn = H / 256;
+                if (rbn > sa.row_bands) { sa.row_bands = rbn; sa.rows_per_band = (H + rbn - 1) / rbn; }
+                const dim3 sgrid((sa.row_bands * sa.col_bands + 3) / 4, n);
+                if (sa.nlev <= 4) k_pyramid_stream_w<4><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
+                else k_pyramid_stream_w<8><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
+            }
+            TRL_LAUNCH_CHECK();
+            for (int q = 0; q < gn; q++) streamed[lv_idx[g0 + q]] = true;
         }
-        if (sa.nlev == 0 || stab_words > STAB || n > 65535) return TRL_OK;
-        // Frames wider than one 4096-byte column band need several bands per row; measured at 1080p and 4K the pass then
-        // gains nothing over the per-level kernels and the PNet launch that follows runs 7-10 % slower: keep it to one band.
-        static const bool wide_env = trl_tune_int("TRL_PYR_STREAM_WIDE", 0) != 0;
-        if (W * 3 > SBYTES && !wide_env) return TRL_OK;
-        sa.H = H; sa.W = W; sa.n_frames = n; sa.pyr_stride = a.pyr_stride;
-        if (W * 3 <= SBYTES) { sa.col_bands = 1; sa.cols_per_band = W; }
-        else { sa.cols_per_band = SBYTES / 3 - kwm - 2; sa.col_bands = (W + sa.cols_per_band - 1) / sa.cols_per_band; }
-        sa.row_bands = H >= 256 ? row_bands : 1;
-        sa.rows_per_band = (H + sa.row_bands - 1) / sa.row_bands;
-        sa.f0 = 0;                                  // every source row is read once: no Infinity-Cache chunking needed
-        const dim3 sgrid(sa.row_bands * sa.col_bands, n);
-        if (sa.nlev <= 4) k_pyramid_stream<4><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
-        else if (sa.nlev <= 8) k_pyramid_stream<8><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
-        else k_pyramid_stream<SMAXL><<<sgrid, 256, 0, s>>>(d_frames, sa, c->pyr_tab, pyr);
-        TRL_LAUNCH_CHECK();
-        for (int l = 0; l < a.L; l++) streamed[l] = streamed[l] || picked[l];
         return TRL_OK;
     };
     if (!stream_off) {
