@@ -6,6 +6,7 @@
 # the timeline and the PMC passes use one batch in flight (--in-flight 1) so that a step's launches are not interleaved with
 # another context's -- since round 4 that is the bench's default; `--in-flight 2` is a variant.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+make -C "$GRAFT_REPO_ROOT/truely-real-time-ai-generated-video-detection-framework-for-social-platforms_amd/csrc" TUNING=1 -j8 -s   # the tuning build (TRL_* switches), if it is not there yet
 O=gpurun_out/refresh
 TUNE_LIB="$GRAFT_REPO_ROOT/truely-real-time-ai-generated-video-detection-framework-for-social-platforms_amd/libtruely_hip_tuning.so"   # TRL_* switches: tuning build only
 rm -rf $O && mkdir -p $O
