@@ -537,6 +537,75 @@ def test_run_cleans_up_when_analysis_fails(tmp_path, monkeypatch):
     assert model.run(src, dst) == 0 and released == [src, src]
 
 
+def test_window_reader_reads_what_is_needed(tmp_path):
+    """model._WindowReader (run()'s reader thread) on the containers with fixed-size frames: with the output stage skipped only the
+    SAMPLED frames are read (positioned reads into the slot), with a 4:2:0 source and the output on every frame lands in the slot,
+    with a BGR source and the output on every frame becomes a host array and the sampled ones are copied to the slot; windows are
+    ragged at the end of the clip; slots are handed back and reused; YUV4MPEG2 frames arrive planar (I420), as stored."""
+    from truely_amd import model
+    from truely_amd.ingest import bgr_to_nv12
+    H, W, step, win = 24, 32, 4, 3
+    fr = np.random.default_rng(4).integers(0, 256, (29, H, W, 3), dtype=np.uint8)      # 29 frames: windows of 12, 12, 5
+    nv = bgr_to_nv12(fr)
+    a, b, c = str(tmp_path / "a.trlv"), str(tmp_path / "b.trlv"), str(tmp_path / "c.y4m")
+    video_io.write_raw(a, fr, 30.0)
+    video_io.write_raw(b, nv, 30.0, pixfmt="nv12", size=(W, H))
+    video_io.write_y4m(c, nv, 30, (W, H))
+
+    def drain(path, all_rows, keep_host, rows):
+        cap = video_io.open_reader(path)[0]
+        slots = [np.full((rows, cap.frame_bytes), 0xEE, np.uint8) for _ in range(2)]
+        rd = model._WindowReader(cap, step, win, slots, all_rows, keep_host, (H, W, 3))
+        assert rd.random
+        for k in range(2):
+            rd.free.put((k, None))
+        rd.start()
+        got = []
+        while True:
+            item = rd.full.get(timeout=30)
+            if item is None:
+                break
+            assert not isinstance(item, BaseException), item
+            slot, nrows, first, nfr, host = item
+            got.append((nrows, first, nfr, slots[slot][:nrows].copy(), host))
+            rd.free.put((slot, None))                 # two slots, three windows: the first one is reused
+        rd.join(10)
+        cap.release()
+        assert rd.frame_count == 29 and [(g[1], g[2]) for g in got] == [(0, 12), (12, 12), (24, 5)]
+        return got
+
+    got = drain(a, False, False, win)                  # BGR, output skipped: sampled frames only
+    assert [g[0] for g in got] == [3, 3, 2]
+    for nrows, first, nfr, rows, host in got:
+        assert host is None
+        for r in range(nrows):
+            assert np.array_equal(rows[r], fr[first + r * step].reshape(-1))
+    got = drain(a, False, True, win)                   # BGR, output written: every frame on the host, sampled ones in the slot
+    for nrows, first, nfr, rows, host in got:
+        assert len(host) == nfr and all(np.array_equal(host[k], fr[first + k]) for k in range(nfr))
+        assert all(np.array_equal(rows[r], fr[first + r * step].reshape(-1)) for r in range(nrows))
+    got = drain(b, True, False, win * step)            # NV12, output written: every frame in the slot (converted on the device later)
+    assert [g[0] for g in got] == [12, 12, 5]
+    assert all(np.array_equal(g[3][k], nv[g[1] + k]) for g in got for k in range(g[0]))
+    got = drain(c, False, False, win)                  # YUV4MPEG2: planar frames as stored (no repacking on the host)
+    ys = H * W
+    for nrows, first, nfr, rows, host in got:
+        for r in range(nrows):
+            f = nv[first + r * step]
+            assert np.array_equal(rows[r][:ys], f[:ys]) and np.array_equal(rows[r][ys:ys + ys // 4], f[ys::2]) and np.array_equal(rows[r][ys + ys // 4:], f[ys + 1::2])
+    # a consumer that goes away: the reader ends instead of blocking on its queue
+    cap = video_io.open_reader(a)[0]
+    rd = model._WindowReader(cap, step, win, [np.zeros((win, cap.frame_bytes), np.uint8)], False, False, (H, W, 3))
+    rd.free.put((0, None))
+    rd.start()
+    assert rd.full.get(timeout=30)[1] == 3
+    rd.stop = True
+    rd.free.put(None)
+    rd.join(10)
+    assert not rd.is_alive()
+    cap.release()
+
+
 def test_analysis_service_spreads_requests_over_gpus():
     """f3 widened: AnalysisService(gpus=[...]) keeps one worker (and engine) per GPU and hands each request to the least-loaded
     one; a GPU's requests stay in arrival order; failures free their slot."""
