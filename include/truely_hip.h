@@ -174,6 +174,11 @@ int  trl_debug_level_counts(trl_ctx* ctx, int frame, int32_t* h_cand, int32_t* h
  * rows of 40 bytes {x1,y1,x2,y2,score,r0,r1,r2,r3 : f32; cell : i32}, cell = y*ow + x of the PNet output map.  With
  * thr0 = 0 every cell is a candidate, so this reads the fused kernel's own probability / regression maps. */
 int  trl_debug_level_cands(trl_ctx* ctx, int frame, int level, void* h_rows, int max_rows, int* n_out);
+/* The per-level NMS picks (detect_face.py stage 1: batched_nms 0.5 per scale) of one (frame, level) of the last call: indices into
+ * the rows trl_debug_level_cands returns (append order), in pick order.  With it a test can check the keep set of a list of ANY
+ * length against the definition of greedy NMS (a box is kept iff no kept box of higher priority overlaps it by more than the
+ * threshold) without an O(n^2) reference run. (ABI v7) */
+int  trl_debug_level_keep(trl_ctx* ctx, int frame, int level, int32_t* h_idx, int max_rows, int* n_out);
 /* test hook: LDS tiers of the sort + NMS kernels in candidates per list (0 keeps a value; multiples of 4 in [16, 3072]; defaults
  * 512 / 2048).  Lists longer than `full_tier` are sorted and suppressed in global memory (the spill tier); lowering the tiers
  * lets small inputs reach it.  Results never depend on the tiers. (ABI v7) */

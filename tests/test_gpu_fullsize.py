@@ -5,6 +5,7 @@ import pytest
 import torch
 
 import truely_amd
+from conftest import assert_greedy_nms_fixed_point
 
 pytestmark = pytest.mark.gpu
 
@@ -245,6 +246,40 @@ def test_default_engine_on_a_4k_frame_at_a_low_pnet_threshold(blob):
     fr = _frame(2160, 3840, 1, 32)
     tr, st = _check_crowded(eng, orc, fr)
     assert tr["n_cand_scale"][0] > 10000 and st["spill_lists"] >= 1, (tr["n_cand_scale"], st)
+
+
+def test_default_engine_on_the_pathological_4k_frame(blob):
+    """The frame the reference would still accept and no CPU check finishes on: 4K at thr0 = 0.3 fires 736,593 of the finest
+    level's 739,312 PNet cells (1.5 M candidates over 14 levels, 394 k boxes into R-Net).  A DEFAULT engine runs it, and what can be
+    checked at this size without an O(n^2) reference is checked exactly: the candidate records of three levels against the
+    oracle's PNet maps (counts, scores, regressions, generateBoundingBox boxes), and the per-level NMS picks of those levels --
+    lists of up to 736 k entries through the spill tier -- against the DEFINITION of greedy NMS (a fixed point that is unique)."""
+    from oracle.oracle import Oracle
+    from truely_amd.engine import Engine
+    eng = Engine(blob, thresholds=(0.3, 0.7, 0.7))
+    orc = Oracle(blob)
+    fr = _frame(2160, 3840, 1, 32)
+    out = eng.detect_embed(fr)
+    st = eng.list_stats()
+    assert st["max_level_count"] > 700000 and st["spill_lists"] >= 8, st
+    cand, keep = eng.level_counts(0)
+    scales = orc.scales(2160, 3840)
+    assert len(cand) == len(scales) == 14
+    for lvl in (0, 2, 6):
+        sc, h, w = scales[lvl]
+        prob, reg = orc.pnet_level(orc.area_resample_norm(fr[0], 0, 2160, 0, 3840, h, w))
+        oh, ow = prob.shape
+        rec, idx = eng.level_keep(0, lvl)
+        assert len(rec) == cand[lvl] == int((prob >= np.float32(0.3)).sum()) and len(idx) == keep[lvl], lvl
+        cy, cx = rec["cell"] // ow, rec["cell"] % ow
+        assert np.array_equal(rec["score"], prob[cy, cx]) and np.array_equal(rec["reg"], reg[cy, cx]), lvl
+        fs = np.float32(sc)
+        fx, fy = cx.astype(np.float32), cy.astype(np.float32)
+        exp = np.stack([np.floor((np.float32(2) * fx + np.float32(1)) / fs), np.floor((np.float32(2) * fy + np.float32(1)) / fs),
+                        np.floor((np.float32(2) * fx + np.float32(12)) / fs), np.floor((np.float32(2) * fy + np.float32(12)) / fs)], axis=1)
+        assert np.array_equal(rec["box"], exp), lvl
+        assert_greedy_nms_fixed_point(rec, idx, oh, ow, 0.5)
+    assert out["valid"].shape == (1,)
 
 
 def test_frames_without_candidates(engine, oracle):

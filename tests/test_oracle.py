@@ -226,3 +226,27 @@ def test_reciprocal_division_is_exact(oracle):
     (csrc/trl_pnet.hip:pyr_div, enabled for bins <= 96).  Every (kh, kw, sum) triple must reproduce the two
     IEEE divisions of the reference expression bit for bit -- exhaustive, ~5.5e9 cases, a few seconds."""
     assert oracle.selftest_recip_div(96) == 0
+
+
+def test_greedy_nms_fixed_point_checker(oracle):
+    """tests/conftest.py::assert_greedy_nms_fixed_point (the size-independent check the GPU suite applies to per-level pick lists of
+    up to 736 k entries) against the oracle's own NMS on a PNet-like cell grid with many score ties: it accepts the sequential
+    algorithm's picks and rejects a pick list with one entry removed or one suppressed box added."""
+    from conftest import assert_greedy_nms_fixed_point
+    rng = np.random.default_rng(0)
+    oh, ow, sc = 40, 55, np.float32(0.6)
+    cell = np.nonzero(rng.uniform(size=oh * ow) < 0.7)[0].astype(np.int32)
+    cy, cx = (cell // ow).astype(np.float32), (cell % ow).astype(np.float32)
+    score = rng.choice(np.linspace(0.3, 0.99, 50).astype(np.float32), size=len(cell))
+    box = np.stack([np.floor((2 * cx + 1) / sc), np.floor((2 * cy + 1) / sc), np.floor((2 * cx + 12) / sc), np.floor((2 * cy + 12) / sc)], 1).astype(np.float32)
+    keep = oracle.nms_iou(box, score, 0.5)                 # stable descending sort: ties -> lower index = lower cell first
+    rec = np.zeros(len(cell), np.dtype([("box", np.float32, 4), ("score", np.float32), ("reg", np.float32, 4), ("cell", np.int32)]))
+    rec["box"], rec["score"], rec["cell"] = box, score, cell
+    assert 100 < len(keep) < len(cell)
+    assert_greedy_nms_fixed_point(rec, keep.astype(np.int32), oh, ow, 0.5)
+    with pytest.raises(AssertionError):
+        assert_greedy_nms_fixed_point(rec, np.delete(keep, 5).astype(np.int32), oh, ow, 0.5)
+    dropped = np.setdiff1d(np.arange(len(cell)), keep)[:1]
+    pos = np.searchsorted(-score[keep], -score[dropped[0]], side="right")
+    with pytest.raises(AssertionError):
+        assert_greedy_nms_fixed_point(rec, np.insert(keep, pos, dropped[0]).astype(np.int32), oh, ow, 0.5)

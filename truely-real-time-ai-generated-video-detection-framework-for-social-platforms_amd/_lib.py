@@ -48,6 +48,7 @@ _SIGNATURES = {
     "trl_debug_stage_boxes": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "trl_debug_level_counts": (C.c_int, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
     "trl_debug_level_cands": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
+    "trl_debug_level_keep": (C.c_int, [_vp, _i, _i, _vp, _i, C.POINTER(_i)]),
     "trl_debug_batch_capacity": (C.c_int, [_vp, _f, _f, C.POINTER(_i)]),
     "trl_debug_nms_tiers": (C.c_int, [_vp, _i, _i]),
     "trl_debug_option": (C.c_int, [_vp, C.c_char_p, _i]),

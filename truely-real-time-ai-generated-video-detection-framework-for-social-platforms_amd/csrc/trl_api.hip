@@ -628,6 +628,23 @@ int trl_debug_level_cands(trl_ctx* c, int frame, int level, void* h_rows, int ma
     return TRL_OK;
 }
 
+// The per-level NMS picks of one (frame, level) of the last call: indices into that level's candidate records (the rows
+// trl_debug_level_cands returns, in the same append order), in pick order (descending score)
+int trl_debug_level_keep(trl_ctx* c, int frame, int level, int32_t* h_idx, int max_rows, int* n_out) {
+    TRL_CHECK(check_idle(c));
+    if (!c->cb.lvl_keep_cnt || frame < 0 || frame >= c->cb.n || level < 0 || level >= c->cb.L || !n_out || (max_rows > 0 && !h_idx)) {
+        trl_set_error("no cascade state");
+        return TRL_ERR_STATE;
+    }
+    TRL_HIP(hipDeviceSynchronize());
+    int32_t k = 0;
+    TRL_HIP(hipMemcpy(&k, c->cb.lvl_keep_cnt + (size_t)frame * c->cb.L + level, 4, hipMemcpyDeviceToHost));
+    *n_out = k;
+    const int m = k < max_rows ? k : max_rows;
+    if (m > 0) TRL_HIP(hipMemcpy(h_idx, c->cb.lvl_keep_idx + (size_t)frame * c->cb.lay.S + c->cb.lay.rec0[level], (size_t)m * 4, hipMemcpyDeviceToHost));
+    return TRL_OK;
+}
+
 int trl_debug_pyramid_level(trl_ctx* c, const uint8_t* d_frame, int H, int W, int level, float* d_out, int* h, int* w, void* stream) {
     TRL_CHECK(check_call(c, d_frame, 1, H, W));
     hipStream_t s = (hipStream_t)stream;

@@ -312,6 +312,19 @@ class Engine:
 
     CAND_DTYPE = np.dtype([("box", np.float32, 4), ("score", np.float32), ("reg", np.float32, 4), ("cell", np.int32)])
 
+    def level_keep(self, frame: int, level: int):
+        """Test hook: (records in APPEND order, pick list) of one (frame, level) of the last call: the pick list holds indices into
+        the records, in pick order (descending score) -- the per-level batched_nms(0.5) of detect_face()."""
+        k = C.c_int()
+        _lib.check(self.lib.trl_debug_level_cands(self._h, int(frame), int(level), None, 0, C.byref(k)))
+        rec = np.zeros((max(1, k.value),), self.CAND_DTYPE)
+        _lib.check(self.lib.trl_debug_level_cands(self._h, int(frame), int(level), rec.ctypes.data_as(C.c_void_p), len(rec), C.byref(k)))
+        rec = rec[:k.value]
+        _lib.check(self.lib.trl_debug_level_keep(self._h, int(frame), int(level), None, 0, C.byref(k)))
+        idx = np.zeros((max(1, k.value),), np.int32)
+        _lib.check(self.lib.trl_debug_level_keep(self._h, int(frame), int(level), idx.ctypes.data_as(C.c_void_p), len(idx), C.byref(k)))
+        return rec, idx[:k.value]
+
     def level_cands(self, frame: int, level: int) -> np.ndarray:
         """Test hook: the candidate records the PNet kernel appended for (frame, level) in the last call, sorted by cell."""
         k = C.c_int()
