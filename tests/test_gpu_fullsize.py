@@ -279,6 +279,39 @@ def test_default_engine_on_the_pathological_4k_frame(blob):
                         np.floor((np.float32(2) * fx + np.float32(12)) / fs), np.floor((np.float32(2) * fy + np.float32(12)) / fs)], axis=1)
         assert np.array_equal(rec["box"], exp), lvl
         assert_greedy_nms_fixed_point(rec, idx, oh, ow, 0.5)
+    # Stage 1b (batched_nms 0.7 over all levels, 394 k boxes, one list through the spill tier) and the stage-1 boxes.  Boxes of
+    # different levels cannot reach IoU 0.7 (IoU <= min area / max area, checked from the records), and inside a level the 0.5
+    # survivors cannot either: the 0.7 pass keeps everything, so the stage-1 list is every level's picks merged by score (ties:
+    # level order, then pick order), regressed with the PNet offsets (w, h without +1), squared (rerec), minus the boxes whose
+    # clipped window is empty -- all of it float32 arithmetic that numpy reproduces operation by operation.
+    recs = [eng.level_keep(0, l) for l in range(len(cand))]
+    picks = [r[i] for r, i in recs]
+    amin = [float(((p["box"][:, 2] - p["box"][:, 0]) * (p["box"][:, 3] - p["box"][:, 1])).min()) if len(p) else None for p in picks]
+    amax = [float(((p["box"][:, 2] - p["box"][:, 0]) * (p["box"][:, 3] - p["box"][:, 1])).max()) if len(p) else None for p in picks]
+    live = [l for l in range(len(picks)) if len(picks[l])]
+    for a in live:
+        for b in live:
+            if a < b:
+                assert amax[a] / amin[b] < 0.7, (a, b)      # finer level a: smaller boxes
+    allp = np.concatenate([picks[l] for l in live])
+    order = np.argsort(-allp["score"].astype(np.float64), kind="stable")          # descending score, ties in concatenation order
+    c = allp[order]
+    x1, y1, x2, y2 = (c["box"][:, q] for q in range(4))
+    rw, rh = x2 - x1, y2 - y1
+    bx1, by1 = x1 + c["reg"][:, 0] * rw, y1 + c["reg"][:, 1] * rh
+    bx2, by2 = x2 + c["reg"][:, 2] * rw, y2 + c["reg"][:, 3] * rh
+    h, w = by2 - by1, bx2 - bx1
+    side = np.maximum(w, h)
+    half = np.float32(0.5)
+    qx1 = bx1 + w * half - side * half
+    qy1 = by1 + h * half - side * half
+    qx2, qy2 = qx1 + side, qy1 + side
+    tx, ty, tex, tey = (np.trunc(v).astype(np.int64) for v in (qx1, qy1, qx2, qy2))
+    ok = (np.minimum(tey, 2160) > np.maximum(ty, 1) - 1) & (np.minimum(tex, 3840) > np.maximum(tx, 1) - 1)
+    exp1 = np.stack([qx1, qy1, qx2, qy2, c["score"]], axis=1)[ok].astype(np.float32)
+    got1 = eng.stage_boxes(1, 0)
+    assert got1.shape == exp1.shape and len(got1) > 300000
+    assert np.array_equal(got1, exp1)
     assert out["valid"].shape == (1,)
 
 
