@@ -537,6 +537,88 @@ def test_run_cleans_up_when_analysis_fails(tmp_path, monkeypatch):
     assert model.run(src, dst) == 0 and released == [src, src]
 
 
+def test_opencv_branches_with_a_recording_stand_in(tmp_path, monkeypatch):
+    """The branches taken when `cv2` IS importable (it is not in this image, so nothing else executes them): a stand-in object
+    that records its calls is put in cv2's place.  The reader hands back the capture with the reference's int() truncation of
+    the frame rate (server/model.py:28: 29.97 -> 29), the writer is opened as model.py:35-36 opens it (fourcc "H264", fps,
+    (w, h)), the annotations are model.py:67-74's calls argument for argument, and run()'s reader thread walks a capture object
+    through cap.read() (the sequential path every compressed source takes)."""
+    from truely_amd import annotate, model
+    calls = []
+    frames = np.random.default_rng(0).integers(0, 256, (9, 24, 32, 3), dtype=np.uint8)
+
+    class Cap:
+        def __init__(self, path):
+            calls.append(("VideoCapture", path)); self.i = 0; self.open = path.endswith(".mp4")
+        def isOpened(self):
+            return self.open
+        def get(self, prop):
+            return {5: 29.97, 3: 32.0, 4: 24.0}[prop]
+        def read(self):
+            if self.i >= len(frames):
+                return False, None
+            self.i += 1
+            return True, frames[self.i - 1].copy()
+        def release(self):
+            calls.append(("release",))
+
+    class FakeCv2:
+        CAP_PROP_FPS, CAP_PROP_FRAME_WIDTH, CAP_PROP_FRAME_HEIGHT = 5, 3, 4
+        FONT_HERSHEY_SIMPLEX, LINE_AA = 0, 16
+        VideoCapture = Cap
+        @staticmethod
+        def VideoWriter_fourcc(*c):
+            return "".join(c)
+        @staticmethod
+        def VideoWriter(path, fourcc, fps, size):
+            calls.append(("VideoWriter", path, fourcc, fps, size)); return "writer"
+        @staticmethod
+        def rectangle(frame, p1, p2, color, thickness):
+            calls.append(("rectangle", p1, p2, color, thickness))
+        @staticmethod
+        def putText(frame, text, org, font, scale, color, thickness, line):
+            calls.append(("putText", text, org, font, scale, color, thickness, line))
+
+    monkeypatch.setattr(video_io, "cv2", FakeCv2)
+    monkeypatch.setattr(annotate, "cv2", FakeCv2)
+    clip = tmp_path / "clip.mp4"; clip.write_bytes(b"\x00\x00\x00\x18ftypmp42 not really")
+    cap, fps, w, h = video_io.open_reader(str(clip))
+    assert (fps, w, h) == (29, 32, 24) and isinstance(cap, Cap)               # int(29.97) = 29 -> step 4 (model.py:28,40)
+    bad = tmp_path / "clip.mov"; bad.write_bytes(b"junk junk junk")
+    assert video_io.open_reader(str(bad)) is None                               # cap.isOpened() false -> "couldn't open" (model.py:24-26)
+    assert video_io.open_writer(str(tmp_path / "out.mp4"), 29, (32, 24)) == "writer"
+    assert ("VideoWriter", str(tmp_path / "out.mp4"), "H264", 29, (32, 24)) in calls
+    calls.clear()
+    img = np.zeros((24, 32, 3), np.uint8)
+    annotate.annotate(img, 12, (3, 4, 20, 21), True)
+    annotate.annotate(img, 16, (3, 4, 20, 21), False)
+    assert calls == [("rectangle", (3, 4), (20, 21), (0, 0, 255), 2),
+                     ("putText", "AI Detected - Frame 12", (10, 30), 0, 1, (0, 0, 255), 2, 16),
+                     ("rectangle", (3, 4), (20, 21), (0, 255, 0), 2),
+                     ("putText", "Real Frame", (3, -6), 0, 0.5, (0, 255, 0), 2, 16)]
+    assert not img.any()                                                       # OpenCV draws when it is there, not this module
+    # run()'s reader thread over such a capture: sampled frames into the slot, every frame kept for the writer
+    slots = [np.zeros((2, 24 * 32 * 3), np.uint8) for _ in range(2)]
+    rd = model._WindowReader(cap, 4, 2, slots, False, True, (24, 32, 3))
+    assert not rd.random
+    for k in range(2):
+        rd.free.put((k, None))
+    rd.start()
+    got = []
+    while True:
+        item = rd.full.get(timeout=30)
+        if item is None:
+            break
+        assert not isinstance(item, BaseException), item
+        slot, nrows, first, nfr, host = item
+        got.append((nrows, first, nfr, slots[slot][:nrows].copy(), host))
+        rd.free.put((slot, None))
+    rd.join(10)
+    assert [(g[0], g[1], g[2]) for g in got] == [(2, 0, 8), (1, 8, 1)] and rd.frame_count == 9
+    assert np.array_equal(got[0][3][1], frames[4].reshape(-1)) and np.array_equal(got[1][3][0], frames[8].reshape(-1))
+    assert all(np.array_equal(got[0][4][k], frames[k]) for k in range(8))
+
+
 def test_window_reader_reads_what_is_needed(tmp_path):
     """model._WindowReader (run()'s reader thread) on the containers with fixed-size frames: with the output stage skipped only the
     SAMPLED frames are read (positioned reads into the slot), with a 4:2:0 source and the output on every frame lands in the slot,
