@@ -127,6 +127,39 @@ def test_bench_flop_model_matches_survey():
     assert abs(bench.pnet_macs(360, 640) / 1e6 - 281.2) < 0.1
 
 
+def test_committed_bench_line_keeps_the_contract():
+    """The newest committed bench line (profiles/roundN_bench.json, written by the driver's command on the GPU box) carries every
+    field the measurement contract names, with consistent values: BASELINE's metric and workload, whole-job throughput =
+    frames x steps / time, the roofline object of the dominant kernel (achieved = algorithmic FLOPs / measured launch duration,
+    frac = achieved / peak) and the CPU baseline of the oracle port on a bounded sample."""
+    import glob
+    import json
+    import bench
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_bench.json")))
+    assert paths
+    d = json.loads(open(paths[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("frames/sec") and d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    cfg = d["config"]
+    assert "configs[1]" in cfg["workload"] and "model" not in cfg and (cfg["frames_per_gpu"], cfg["height"], cfg["width"]) == (256, 720, 1280)
+    assert abs(d["value"] - cfg["frames_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-3
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == bench.PEAK_F32_MFMA_TFLOPS
+    flops = 2.0 * bench.pnet_macs(720, 1280) * 256
+    assert abs(r["flop_per_step"] - flops) / flops < 1e-6
+    assert abs(r["achieved"] - flops / (r["kernel_ms_per_step"] / 1e3) / 1e12) < 0.05 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["kernel_ms_per_step"] < d["ms_per_step"] and 0.3 < r["frac"] < 1.0 and r["traffic"] > 2.0e9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and 0 < c["value"] < d["value"]
+
+
 def test_bench_multi_gpu_launch_is_correct_by_construction():
     """The 8-GPU run is the driver's to launch (no node here): what can be checked without hardware.  `--gpus 8` without a
     launcher starts torch.distributed.run with 8 ranks on this node, rendezvous on 127.0.0.1, dmabuf IPC for RCCL, and passes the
